@@ -1,0 +1,152 @@
+/*
+ * wfe.h -- C ABI of the MI355X (gfx950) Whisper audio front end.
+ *
+ * The reference (cttailearn/Whisper-Finetune) has no FFI for this path: the
+ * boundary there is two duck-typed Python objects.  These entry
+ * points are what a binding for that boundary calls; each one names the
+ * reference interface it stands in for.  "HF:" = transformers/models/whisper/
+ * feature_extraction_whisper.py (third-party, called from utils/reader.py:192,
+ * 195,198 and infer_tfs.py:37).
+ *
+ * Conventions: every function returns 0 on success and a negative wfe_status on
+ * failure, never throws, never takes ownership of caller buffers, and is
+ * stream-ordered (asynchronous) with respect to `stream` (a hipStream_t passed
+ * as void*; NULL = the null stream).  Device pointers must belong to the
+ * handle's device.  One host thread per handle at a time.
+ */
+#ifndef WFE_H
+#define WFE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WFE_N_FFT 400
+#define WFE_HOP 160
+#define WFE_N_FREQ 201
+#define WFE_MAX_MEL 128
+
+typedef enum {
+  WFE_OK = 0,
+  WFE_ERR_ARG = -1,       /* bad argument (null pointer, shape, unsupported size) */
+  WFE_ERR_HIP = -2,       /* a HIP runtime call failed; see wfe_last_error */
+  WFE_ERR_ALLOC = -3,     /* allocation failure */
+  WFE_ERR_SAMPLING = -4   /* sampling rate is not the extractor's (HF:265-271 ValueError) */
+} wfe_status;
+
+typedef struct wfe_context* wfe_handle;
+
+/* Mirrors WhisperFeatureExtractor.__init__ (HF:69-103): feature_size, sampling
+ * rate, hop, n_fft.  Only n_fft=400 / hop=160 (every Whisper checkpoint) are
+ * implemented by the kernels; anything else is WFE_ERR_ARG. */
+typedef struct {
+  int32_t n_mel;          /* feature_size: 1..128 (80 tiny..large-v2, 128 large-v3) */
+  int32_t n_fft;          /* 400 */
+  int32_t hop_length;     /* 160 */
+  int32_t sampling_rate;  /* 16000 */
+  int32_t device;         /* HIP device ordinal */
+} wfe_config;
+
+/* ---- augmentation (utils/reader.py:246-340) ------------------------------ */
+/* One entry of a per-utterance op list.  The host draws the decisions in the
+ * reference's order (utils/reader.py:246-278) and passes the results; the
+ * kernels apply them while staging the waveform.  Ops are listed in
+ * application order. */
+typedef enum {
+  WFE_AUG_SPEED = 1,   /* change_speed  utils/reader.py:281-292 */
+  WFE_AUG_SHIFT = 2,   /* shift         utils/reader.py:295-307 */
+  WFE_AUG_VOLUME = 3,  /* volume        utils/reader.py:310-313 */
+  WFE_AUG_NOISE = 4,   /* add_noise     utils/reader.py:322-340 */
+  WFE_AUG_AFFINE = 5   /* (x - mean) * rstd on the kept prefix: zero_mean_unit_var_norm HF:172-191 */
+} wfe_aug_kind;
+
+typedef struct {
+  int32_t kind;        /* wfe_aug_kind */
+  int32_t i0;          /* SPEED: new length int(old/rate).  SHIFT: shift in samples (signed,
+                          int(ms*sr/1000)).  NOISE: noise clip index */
+  int32_t i1;          /* NOISE: start frame inside the noise clip (0 unless the clip is longer
+                          than the sample, utils/reader.py:336-338) */
+  int32_t i2;          /* NOISE: snr in dB */
+  float   f0;          /* VOLUME: the float32 multiplier float32(10.**(gain/20.)) */
+  float   f1;          /* reserved, 0 */
+  double  d0;          /* reserved, 0 */
+} wfe_aug_op;          /* 32 bytes; at most one SPEED op per utterance */
+
+/* ---- lifetime ------------------------------------------------------------ */
+/* WhisperFeatureExtractor(feature_size=...) (HF:69-103): builds the Hann/DFT and
+ * slaney mel tables in float64 on the host (audio_utils.py:638-729), rounds
+ * once to float32 and uploads them. */
+int wfe_create(const wfe_config* cfg, wfe_handle* out);
+int wfe_destroy(wfe_handle h);
+/* Text of the last failure on this handle (or of the last failed wfe_create
+ * when h is NULL).  Valid until the next call on the same handle. */
+const char* wfe_last_error(wfe_handle h);
+
+/* self.mel_filters (HF:95-103): (201, n_mel) row-major float64, host memory. */
+int wfe_mel_filters(wfe_handle h, double* host_out);
+
+/* ---- hot path ------------------------------------------------------------ */
+/* WhisperFeatureExtractor.__call__ minus the Python wrapping (HF:300-330):
+ * truncate each utterance to n_samples, right-pad with zeros, reflect-padded
+ * 400-point Hann STFT with hop 160 (last frame dropped), power, mel
+ * projection, log10 floored at 1e-10, per-utterance max-8 clamp, (x+4)/4.
+ *
+ *   wav        device, float32.  Utterance b starts at wav + offsets[b]
+ *              (offsets != NULL, device int64) or wav + b*row_stride.
+ *   lengths    device int32[batch], samples present for each utterance (may
+ *              exceed n_samples: truncated; may be 0).
+ *   n_samples  padded length; 480000 for the default padding="max_length",
+ *              the longest clip for padding="longest".  Must be > 200.
+ *   out        device float32 (batch, n_mel, n_samples/160), fully overwritten.
+ */
+int wfe_logmel(wfe_handle h, const float* wav, const int64_t* offsets, const int32_t* lengths,
+               int64_t row_stride, int32_t batch, int32_t n_samples, float* out, void* stream);
+
+/* Same transform with the augmentation chain of CustomDataset.augment
+ * (utils/reader.py:246-278) applied to each utterance while it is staged:
+ * utterance b runs ops[op_begin[b] .. op_begin[b+1]).  `lengths` are the RAW
+ * lengths; speed ops change the effective length before pad/trim.
+ *   ops, op_begin   device arrays (op_begin has batch+1 entries; total_ops = op_begin[batch],
+ *                   passed by the host so that no device read-back is needed)
+ *   noise           device float32, all noise clips back to back
+ *   noise_offsets   device int64[n_noise+1] prefix offsets into `noise`
+ */
+int wfe_augment_logmel(wfe_handle h, const float* wav, const int64_t* offsets, const int32_t* lengths,
+                       int64_t row_stride, int32_t batch, int32_t n_samples,
+                       const wfe_aug_op* ops, const int32_t* op_begin, int64_t total_ops,
+                       const float* noise, const int64_t* noise_offsets, int32_t n_noise,
+                       float* out, void* stream);
+
+/* The augmented, padded waveform itself, (batch, n_samples) float32: what
+ * CustomDataset._get_list_data returns (utils/reader.py:134-162) after pad/trim.
+ * Used by the parity tests of the augmentation stages. */
+int wfe_augment_waveform(wfe_handle h, const float* wav, const int64_t* offsets, const int32_t* lengths,
+                         int64_t row_stride, int32_t batch, int32_t n_samples,
+                         const wfe_aug_op* ops, const int32_t* op_begin, int64_t total_ops,
+                         const float* noise, const int64_t* noise_offsets, int32_t n_noise,
+                         float* out, int32_t* out_lengths, void* stream);
+
+/* Stage F4 alone: |STFT|^2 as (batch, 201, n_samples/160) float32 -- the
+ * `magnitudes` tensor of HF:149-154.  For stage-level parity tests. */
+int wfe_power_spectrum(wfe_handle h, const float* wav, const int64_t* offsets, const int32_t* lengths,
+                       int64_t row_stride, int32_t batch, int32_t n_samples, float* out, void* stream);
+
+/* ---- host-only helpers (no GPU needed) ----------------------------------- */
+/* The packed tables exactly as the kernels read them; exported so that CPU
+ * tests can check the folded-DFT algebra and the packing without a device. */
+int64_t wfe_dft_table_floats(void);
+int64_t wfe_mel_table_floats(void);
+int wfe_build_dft_table(float* host_out);
+int wfe_build_mel_table(int32_t n_mel, float* host_out, uint32_t* mask14);
+int wfe_build_mel_filters(int32_t n_mel, double* host_out /* (201, n_mel) */);
+/* n for (parity class, k-step, k-lane) of the folded DFT. */
+int32_t wfe_dft_n_of(int32_t parity_class, int32_t step, int32_t kk);
+
+const char* wfe_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WFE_H */

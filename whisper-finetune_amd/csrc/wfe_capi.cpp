@@ -1,0 +1,303 @@
+// wfe_capi.cpp -- the C ABI declared in include/wfe.h.  Thin: argument checks,
+// table upload at create time, kernel launches.  No torch types, no exceptions
+// across the boundary.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/wfe.h"
+#include "wfe_kernels.h"
+#include "wfe_layout.h"
+
+struct wfe_context {
+  wfe_config cfg;
+  float* d_dft = nullptr;
+  float* d_mel = nullptr;
+  unsigned* d_clip_max = nullptr;       // kMaxBatchPerLaunch words
+  wfe::Resolved* d_resolved = nullptr;  // grows on demand
+  size_t resolved_cap = 0;
+  double* d_noise_meansq = nullptr;     // grows on demand
+  size_t noise_cap = 0;
+  const float* noise_seen = nullptr;    // noise bank whose mean squares are cached
+  const int64_t* noise_off_seen = nullptr;
+  int n_noise_seen = 0;
+  unsigned mel_mask[14];
+  std::vector<double> mel_filters;      // (201, n_mel)
+  std::string err;
+};
+
+namespace {
+
+constexpr int kMaxBatchPerLaunch = 4096;
+thread_local std::string g_create_err;
+
+int fail(wfe_context* h, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf; else g_create_err = buf;
+  return code;
+}
+
+#define HIP_TRY(h, expr)                                                                 \
+  do {                                                                                   \
+    hipError_t e_ = (expr);                                                              \
+    if (e_ != hipSuccess) return fail(h, WFE_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+
+int check_common(wfe_context* h, const float* wav, const int32_t* lengths, int32_t batch, int32_t n_samples,
+                 const void* out) {
+  if (!h) return fail(nullptr, WFE_ERR_ARG, "null handle");
+  if (batch < 0) return fail(h, WFE_ERR_ARG, "batch %d < 0", batch);
+  if (batch > 0 && (!wav || !lengths || !out)) return fail(h, WFE_ERR_ARG, "null device pointer");
+  if (n_samples <= wfe::kHalf)
+    return fail(h, WFE_ERR_ARG, "n_samples %d must exceed n_fft/2 = 200 (reflect padding)", n_samples);
+  if (n_samples / wfe::kHop < 1) return fail(h, WFE_ERR_ARG, "n_samples %d gives no frame", n_samples);
+  if ((long long)n_samples + wfe::kNfft >= (1LL << 30)) return fail(h, WFE_ERR_ARG, "n_samples too large");
+  return WFE_OK;
+}
+
+void fill_args(wfe_context* h, wfe::FrontArgs& a, const float* wav, const int64_t* offsets, const int32_t* lengths,
+               int64_t row_stride, int32_t n_samples) {
+  std::memset(&a, 0, sizeof a);
+  a.wav = wav;
+  a.offsets = reinterpret_cast<const long long*>(offsets);
+  a.lengths = lengths;
+  a.row_stride = row_stride;
+  a.n_samples = n_samples;
+  a.n_frames = n_samples / wfe::kHop;
+  a.n_mel = h->cfg.n_mel;
+  a.dft_tab = h->d_dft;
+  a.mel_tab = h->d_mel;
+  std::memcpy(a.mel_mask, h->mel_mask, sizeof a.mel_mask);
+  a.clip_max = h->d_clip_max;
+}
+
+// Batch sliced into launches of at most kMaxBatchPerLaunch utterances.
+struct Slice {
+  int begin, count;
+};
+std::vector<Slice> slices(int batch) {
+  std::vector<Slice> v;
+  for (int b = 0; b < batch; b += kMaxBatchPerLaunch)
+    v.push_back({b, batch - b < kMaxBatchPerLaunch ? batch - b : kMaxBatchPerLaunch});
+  return v;
+}
+
+int ensure_aug_workspace(wfe_context* h, size_t total_ops, const float* noise, const int64_t* noise_off, int n_noise,
+                         hipStream_t stream) {
+  if (total_ops > h->resolved_cap) {
+    if (h->d_resolved) HIP_TRY(h, hipFree(h->d_resolved));
+    h->d_resolved = nullptr;
+    h->resolved_cap = 0;
+    size_t cap = total_ops < 1024 ? 1024 : total_ops * 2;
+    HIP_TRY(h, hipMalloc(&h->d_resolved, cap * sizeof(wfe::Resolved)));
+    h->resolved_cap = cap;
+  }
+  if (n_noise > 0) {
+    if ((size_t)n_noise > h->noise_cap) {
+      if (h->d_noise_meansq) HIP_TRY(h, hipFree(h->d_noise_meansq));
+      h->d_noise_meansq = nullptr;
+      h->noise_cap = 0;
+      h->noise_seen = nullptr;
+      size_t cap = (size_t)n_noise < 64 ? 64 : (size_t)n_noise * 2;
+      HIP_TRY(h, hipMalloc(&h->d_noise_meansq, cap * sizeof(double)));
+      h->noise_cap = cap;
+    }
+    // The mean squares are recomputed on every call: the bank may have been
+    // refilled in place, and the pass is a few microseconds per clip.
+    HIP_TRY(h, wfe::launch_noise_meansq(noise, reinterpret_cast<const long long*>(noise_off), n_noise,
+                                        h->d_noise_meansq, stream));
+  }
+  return WFE_OK;
+}
+
+int run_frontend(wfe_context* h, const float* wav, const int64_t* offsets, const int32_t* lengths, int64_t row_stride,
+                 int32_t batch, int32_t n_samples, const wfe_aug_op* ops, const int32_t* op_begin, int64_t total_ops,
+                 const float* noise, const int64_t* noise_off, int32_t n_noise, float* out, int mode, void* stream_) {
+  int rc = check_common(h, wav, lengths, batch, n_samples, out);
+  if (rc != WFE_OK) return rc;
+  if (batch == 0) return WFE_OK;
+  const bool aug = ops != nullptr;
+  if (aug && !op_begin) return fail(h, WFE_ERR_ARG, "ops given without op_begin");
+  if (aug && n_noise > 0 && (!noise || !noise_off)) return fail(h, WFE_ERR_ARG, "n_noise > 0 without a noise bank");
+  if (offsets == nullptr && row_stride < 0) return fail(h, WFE_ERR_ARG, "negative row_stride");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DeviceGuard guard(h->cfg.device);
+  if (!guard.ok) return fail(h, WFE_ERR_HIP, "hipSetDevice(%d) failed", h->cfg.device);
+  if (aug) {
+    rc = ensure_aug_workspace(h, (size_t)total_ops, noise, noise_off, n_noise, stream);
+    if (rc != WFE_OK) return rc;
+  }
+  const int T = n_samples / wfe::kHop;
+  const long long per_clip = (mode == 1) ? (long long)wfe::kNfreq * T : (long long)h->cfg.n_mel * T;
+  for (const Slice& s : slices(batch)) {
+    wfe::FrontArgs a;
+    fill_args(h, a, wav, offsets, lengths, row_stride, n_samples);
+    // slice by pointer arithmetic so that blockIdx.y indexes the slice
+    if (offsets) a.offsets += s.begin; else a.wav += (long long)s.begin * row_stride;
+    a.lengths += s.begin;
+    a.out = out + (long long)s.begin * per_clip;
+    if (aug) {
+      a.ops = ops;
+      a.op_begin = op_begin + s.begin;
+      a.noise = noise;
+      a.noise_off = reinterpret_cast<const long long*>(noise_off);
+      a.noise_meansq = h->d_noise_meansq;
+      a.resolved = h->d_resolved;
+      HIP_TRY(h, wfe::launch_resolve(a, s.count, stream));
+    }
+    if (mode == 0) HIP_TRY(h, hipMemsetAsync(h->d_clip_max, 0, sizeof(unsigned) * s.count, stream));
+    HIP_TRY(h, wfe::launch_frontend(a, s.count, mode, aug, stream));
+    if (mode == 0) HIP_TRY(h, wfe::launch_clamp(a.out, h->d_clip_max, s.count, per_clip, stream));
+  }
+  return WFE_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* wfe_version(void) { return "wfe-amd 0.1 (gfx950)"; }
+
+int wfe_create(const wfe_config* cfg, wfe_handle* out) {
+  if (!cfg || !out) return fail(nullptr, WFE_ERR_ARG, "null argument");
+  *out = nullptr;
+  if (cfg->n_fft != wfe::kNfft || cfg->hop_length != wfe::kHop)
+    return fail(nullptr, WFE_ERR_ARG, "only n_fft=400 / hop_length=160 are implemented (got %d / %d)", cfg->n_fft,
+                cfg->hop_length);
+  if (cfg->sampling_rate != 16000)
+    return fail(nullptr, WFE_ERR_SAMPLING, "only sampling_rate=16000 is implemented (got %d)", cfg->sampling_rate);
+  if (cfg->n_mel < 1 || cfg->n_mel > wfe::kMaxMel)
+    return fail(nullptr, WFE_ERR_ARG, "n_mel %d outside 1..%d", cfg->n_mel, wfe::kMaxMel);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail(nullptr, WFE_ERR_HIP, "no HIP device available: the front end has no CPU path");
+  if (cfg->device < 0 || cfg->device >= ndev)
+    return fail(nullptr, WFE_ERR_ARG, "device %d outside 0..%d", cfg->device, ndev - 1);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess)
+    return fail(nullptr, WFE_ERR_HIP, "hipGetDeviceProperties failed");
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, WFE_ERR_HIP, "device %d is %s; this library is built for gfx950 only", cfg->device,
+                prop.gcnArchName);
+
+  wfe_context* h = new (std::nothrow) wfe_context();
+  if (!h) return fail(nullptr, WFE_ERR_ALLOC, "out of host memory");
+  h->cfg = *cfg;
+  h->mel_filters.resize((size_t)wfe::kNfreq * cfg->n_mel);
+  wfe_build_mel_filters(cfg->n_mel, h->mel_filters.data());
+  std::vector<float> dft((size_t)wfe::kDftTableFloats), mel((size_t)wfe::kMelTableFloats);
+  wfe_build_dft_table(dft.data());
+  wfe_build_mel_table(cfg->n_mel, mel.data(), h->mel_mask);
+
+  DeviceGuard guard(cfg->device);
+  hipError_t e = guard.ok ? hipSuccess : hipErrorInvalidDevice;
+  if (e == hipSuccess) e = hipMalloc(&h->d_dft, dft.size() * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&h->d_mel, mel.size() * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc(&h->d_clip_max, sizeof(unsigned) * kMaxBatchPerLaunch);
+  if (e == hipSuccess) e = hipMemcpy(h->d_dft, dft.data(), dft.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(h->d_mel, mel.data(), mel.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    fail(nullptr, WFE_ERR_HIP, "wfe_create: %s", hipGetErrorString(e));
+    wfe_destroy(h);
+    return WFE_ERR_HIP;
+  }
+  *out = h;
+  return WFE_OK;
+}
+
+int wfe_destroy(wfe_handle h) {
+  if (!h) return WFE_OK;
+  DeviceGuard guard(h->cfg.device);
+  if (h->d_dft) (void)hipFree(h->d_dft);
+  if (h->d_mel) (void)hipFree(h->d_mel);
+  if (h->d_clip_max) (void)hipFree(h->d_clip_max);
+  if (h->d_resolved) (void)hipFree(h->d_resolved);
+  if (h->d_noise_meansq) (void)hipFree(h->d_noise_meansq);
+  delete h;
+  return WFE_OK;
+}
+
+const char* wfe_last_error(wfe_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int wfe_mel_filters(wfe_handle h, double* host_out) {
+  if (!h || !host_out) return fail(h, WFE_ERR_ARG, "null argument");
+  std::memcpy(host_out, h->mel_filters.data(), h->mel_filters.size() * sizeof(double));
+  return WFE_OK;
+}
+
+int wfe_logmel(wfe_handle h, const float* wav, const int64_t* offsets, const int32_t* lengths, int64_t row_stride,
+               int32_t batch, int32_t n_samples, float* out, void* stream) {
+  return run_frontend(h, wav, offsets, lengths, row_stride, batch, n_samples, nullptr, nullptr, 0, nullptr, nullptr, 0,
+                      out, 0, stream);
+}
+
+int wfe_power_spectrum(wfe_handle h, const float* wav, const int64_t* offsets, const int32_t* lengths,
+                       int64_t row_stride, int32_t batch, int32_t n_samples, float* out, void* stream) {
+  return run_frontend(h, wav, offsets, lengths, row_stride, batch, n_samples, nullptr, nullptr, 0, nullptr, nullptr, 0,
+                      out, 1, stream);
+}
+
+int wfe_augment_logmel(wfe_handle h, const float* wav, const int64_t* offsets, const int32_t* lengths,
+                       int64_t row_stride, int32_t batch, int32_t n_samples, const wfe_aug_op* ops,
+                       const int32_t* op_begin, int64_t total_ops, const float* noise, const int64_t* noise_offsets,
+                       int32_t n_noise, float* out, void* stream) {
+  if (h && (!ops || !op_begin)) return fail(h, WFE_ERR_ARG, "ops / op_begin must not be null");
+  return run_frontend(h, wav, offsets, lengths, row_stride, batch, n_samples, ops, op_begin, total_ops, noise,
+                      noise_offsets, n_noise, out, 0, stream);
+}
+
+int wfe_augment_waveform(wfe_handle h, const float* wav, const int64_t* offsets, const int32_t* lengths,
+                         int64_t row_stride, int32_t batch, int32_t n_samples, const wfe_aug_op* ops,
+                         const int32_t* op_begin, int64_t total_ops, const float* noise, const int64_t* noise_offsets,
+                         int32_t n_noise, float* out, int32_t* out_lengths, void* stream_) {
+  if (!h) return fail(nullptr, WFE_ERR_ARG, "null handle");
+  if (batch < 0 || n_samples < 1) return fail(h, WFE_ERR_ARG, "bad batch / n_samples");
+  if (batch == 0) return WFE_OK;
+  if (!wav || !lengths || !out || !ops || !op_begin) return fail(h, WFE_ERR_ARG, "null device pointer");
+  if (n_noise > 0 && (!noise || !noise_offsets)) return fail(h, WFE_ERR_ARG, "n_noise > 0 without a noise bank");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DeviceGuard guard(h->cfg.device);
+  if (!guard.ok) return fail(h, WFE_ERR_HIP, "hipSetDevice(%d) failed", h->cfg.device);
+  int rc = ensure_aug_workspace(h, (size_t)total_ops, noise, noise_offsets, n_noise, stream);
+  if (rc != WFE_OK) return rc;
+  for (const Slice& s : slices(batch)) {
+    wfe::FrontArgs a;
+    fill_args(h, a, wav, offsets, lengths, row_stride, n_samples);
+    if (offsets) a.offsets += s.begin; else a.wav += (long long)s.begin * row_stride;
+    a.lengths += s.begin;
+    a.ops = ops;
+    a.op_begin = op_begin + s.begin;
+    a.noise = noise;
+    a.noise_off = reinterpret_cast<const long long*>(noise_offsets);
+    a.noise_meansq = h->d_noise_meansq;
+    a.resolved = h->d_resolved;
+    HIP_TRY(h, wfe::launch_resolve(a, s.count, stream));
+    HIP_TRY(h, wfe::launch_waveform(a, s.count, out + (long long)s.begin * n_samples,
+                                    out_lengths ? out_lengths + s.begin : nullptr, stream));
+  }
+  return WFE_OK;
+}
+
+}  // extern "C"

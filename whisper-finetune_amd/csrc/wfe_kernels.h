@@ -1,0 +1,55 @@
+// wfe_kernels.h -- launch interface between the C ABI (wfe_capi.cpp) and the
+// gfx950 kernels (wfe_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/wfe.h"
+
+namespace wfe {
+
+// Gains of one NOISE op resolved on the device (utils/reader.py:325-331), or
+// mean / std of an AFFINE op.
+struct Resolved {
+  float a;
+  float b;
+};
+
+struct FrontArgs {
+  // input
+  const float* wav;
+  const long long* offsets;      // optional
+  const int* lengths;
+  long long row_stride;
+  int n_samples;                 // padded length (reflect padding applies to this length)
+  int n_frames;                  // n_samples / 160
+  int n_mel;
+  // tables
+  const float* dft_tab;
+  const float* mel_tab;
+  unsigned mel_mask[14];
+  // output
+  float* out;                    // (B, n_mel, T) log10 mel power, or (B, 201, T) power
+  unsigned* clip_max;            // (B) order-preserving encoding of max log10
+  // augmentation (AUG kernels only)
+  const wfe_aug_op* ops;
+  const int* op_begin;
+  const float* noise;
+  const long long* noise_off;
+  const double* noise_meansq;    // (n_noise) mean square of each noise clip
+  Resolved* resolved;            // (total ops) filled by the reduce kernel
+};
+
+// mode 0: log10 mel + clip max.  mode 1: power spectrum.
+hipError_t launch_frontend(const FrontArgs& a, int batch, int mode, bool augmented, hipStream_t stream);
+// (x > max-8 ? x : max-8) + 4) / 4 in place over (batch, per_clip)
+hipError_t launch_clamp(float* out, const unsigned* clip_max, int batch, long long per_clip, hipStream_t stream);
+// mean squares of the noise clips (once per noise bank)
+hipError_t launch_noise_meansq(const float* noise, const long long* noise_off, int n_noise, double* meansq,
+                               hipStream_t stream);
+// resolve the data-dependent scalars of every utterance's chain (NOISE gains, AFFINE stats)
+hipError_t launch_resolve(const FrontArgs& a, int batch, hipStream_t stream);
+// augmented + padded waveform (batch, n_samples) and final lengths
+hipError_t launch_waveform(const FrontArgs& a, int batch, float* out, int* out_lengths, hipStream_t stream);
+
+}  // namespace wfe
