@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- log-mel audio-hours/sec of the HIP front end on N MI355X.
+
+One "step" = one pass of the hot path (pad/trim -> STFT -> mel -> log -> clamp)
+over one batch of 256 synthetic 30 s clips that are already resident in HBM
+(BASELINE.json configs[1]: whisper-small 80-mel front end, batch 256, no
+augmentation).  With N > 1 (launched by torch.distributed.run, one rank per
+GPU) every rank runs its own front end on its own batch -- utterances are
+independent, there is no data-path collective -- so scaling is weak
+and `value` is the sum over ranks.
+
+Prints ONE JSON line on rank 0.  Besides the driver's contract it carries
+  roofline      achieved = SURVEY 8d algorithmic FLOPs (1.061 GF per 30 s clip at
+                80 mel) x clips per launch / mean device time of the STFT+mel
+                kernel, measured with HIP events on the launch stream inside the
+                timed region; peak = 157.3 TFLOP/s (f32 MFMA, MI355X_MICROARCH.md)
+  cpu_baseline  the CPU oracle (a torch.stft restatement of the reference
+                extractor, oracle/logmel.py) timed on this box's host cores on a
+                bounded sample, rank 0 at N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "whisper-finetune_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+SR = 16000
+N_SAMPLES = 480000
+CLIP_HOURS = 30.0 / 3600.0
+ALGO_GFLOP = {80: 1.0613, 128: 1.1192}       # 2*3000*400*402 + 2*3000*201*M
+ALGO_BYTES = {80: 2.88e6, 128: 3.456e6}      # waveform read + log-mel write
+PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def device_clips(batch: int, device, seed0: int) -> torch.Tensor:
+    """SURVEY 8d config 2 recipe (0.1*N(0,1), amplitude-modulated at 3 Hz),
+    generated on the device from per-clip seeds."""
+    t = torch.arange(N_SAMPLES, device=device, dtype=torch.float32) / SR
+    env = 0.5 * (1.0 + torch.sin(2 * np.pi * 3.0 * t))
+    out = torch.empty((batch, N_SAMPLES), dtype=torch.float32, device=device)
+    g = torch.Generator(device=device)
+    for b in range(batch):
+        g.manual_seed(seed0 + b)
+        out[b] = 0.1 * torch.randn(N_SAMPLES, generator=g, device=device, dtype=torch.float32) * env
+    return out
+
+
+def cpu_baseline(n_mel: int, budget_s: float = 20.0) -> dict:
+    """Reference CPU path timed beside the GPU path: per-utterance calls, as
+    CustomDataset.__getitem__ makes them (utils/reader.py:195), all host threads
+    torch gives us.  Bounded to ~budget_s seconds."""
+    from oracle import logmel as ol   # checker / baseline only
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cases
+
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    clips = [cases.synth_clip(i) for i in range(8)]
+    ol.logmel_f32(clips[:1], n_mel=n_mel)                       # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        ol.logmel_f32([clips[n % len(clips)]], n_mel=n_mel)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 4096:
+            break
+    res = {"value": n * CLIP_HOURS / el, "unit": "audio-hours/sec", "cores": cores, "kind": "port",
+           "sample": f"{n} per-utterance calls of oracle.logmel_f32 (torch.stft fp32 restatement of "
+                     f"WhisperFeatureExtractor) on 30 s synthetic clips, {el:.1f} s, torch threads={cores}"}
+    # one batched call for context
+    t1 = time.perf_counter()
+    ol.logmel_f32(clips, n_mel=n_mel)
+    res["batched8_audio_hours_per_sec"] = len(clips) * CLIP_HOURS / (time.perf_counter() - t1)
+    try:   # the third-party class itself, when the box has it (same image): reported beside the port
+        from transformers import WhisperFeatureExtractor
+        fe = WhisperFeatureExtractor(feature_size=n_mel)
+        fe(clips[0], sampling_rate=SR)
+        m, t2 = 0, time.perf_counter()
+        while time.perf_counter() - t2 < 5.0:
+            fe(clips[m % len(clips)], sampling_rate=SR)
+            m += 1
+        res["transformers_extractor_audio_hours_per_sec"] = m * CLIP_HOURS / (time.perf_counter() - t2)
+    except Exception as e:  # noqa: BLE001
+        res["transformers_extractor_audio_hours_per_sec"] = None
+        res["transformers_note"] = f"not timed: {type(e).__name__}"
+    return res
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--n-mel", type=int, default=80)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the front end has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if dist:
+        import torch.distributed as td
+        td.init_process_group("nccl", device_id=device)
+
+    from wfe_amd.frontend import HipFrontEnd
+    fe = HipFrontEnd(n_mel=args.n_mel, device=local_rank)
+    wav = device_clips(args.batch, device, seed0=rank * args.batch)
+    lens = torch.full((args.batch,), N_SAMPLES, dtype=torch.int32, device=device)
+    out = torch.empty((args.batch, args.n_mel, N_SAMPLES // 160), dtype=torch.float32, device=device)
+
+    def barrier():
+        if dist:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        fe.logmel(wav, lens, out=out)
+    barrier()
+    fe.kernel_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fe.logmel(wav, lens, out=out)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    k1_ms, k2_ms, launches = fe.kernel_times()
+    fe.kernel_timing(False)
+
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    checksum = float(out.double().sum().item())
+    if rank == 0:
+        clips = args.batch * args.steps * world
+        k1_avg_s = k1_ms / max(launches, 1) / 1e3
+        achieved = ALGO_GFLOP[args.n_mel] * args.batch / k1_avg_s / 1e3          # TFLOP/s
+        line = {
+            "metric": "log-mel audio-hours/sec",
+            "value": clips * CLIP_HOURS / elapsed,
+            "unit": "audio-hours/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"whisper-small {args.n_mel}-mel front end, batch {args.batch} synthetic 30 s "
+                                   "16 kHz clips per GPU, no augmentation, input resident in HBM",
+                       "batch_per_gpu": args.batch, "n_mel": args.n_mel, "clip_seconds": 30,
+                       "parallelism": f"dp{world} (utterances sharded, no data-path collective)"},
+            "clips_per_sec": clips / elapsed,
+            "roofline": {
+                "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "kernel": "wfe::frontend_kernel", "kernel_ms_avg": k1_avg_s * 1e3, "launches": launches,
+                "algorithmic_gflop_per_clip": ALGO_GFLOP[args.n_mel],
+                "executed_mfma_gflop_per_clip": 2 * 3008 * 4 * 100 * 112 / 1e9,
+                "clamp_kernel_ms_avg": k2_ms / max(launches, 1),
+                "hbm_algorithmic_gbs": ALGO_BYTES[args.n_mel] * args.batch / k1_avg_s / 1e9,
+            },
+            "checksum": checksum,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.n_mel)
+        print(json.dumps(line), flush=True)
+    if dist:
+        td.barrier()
+        td.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -133,6 +133,15 @@ int wfe_augment_waveform(wfe_handle h, const float* wav, const int64_t* offsets,
 int wfe_power_spectrum(wfe_handle h, const float* wav, const int64_t* offsets, const int32_t* lengths,
                        int64_t row_stride, int32_t batch, int32_t n_samples, float* out, void* stream);
 
+/* ---- measurement ---------------------------------------------------------- */
+/* No reference counterpart (the reference has no timing code).
+ * When enabled, every front-end launch is bracketed by HIP events on the
+ * caller's stream; wfe_kernel_times waits for them, returns the summed device
+ * time of the STFT+mel kernel and of the clamp kernel and the number of launches
+ * since the last query, and resets the counters.  Used by bench.py's roofline. */
+int wfe_kernel_timing(wfe_handle h, int32_t enable);
+int wfe_kernel_times(wfe_handle h, double* frontend_ms, double* clamp_ms, int64_t* launches);
+
 /* ---- host-only helpers (no GPU needed) ----------------------------------- */
 /* The packed tables exactly as the kernels read them; exported so that CPU
  * tests can check the folded-DFT algebra and the packing without a device. */

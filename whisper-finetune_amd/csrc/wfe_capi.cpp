@@ -28,6 +28,10 @@ struct wfe_context {
   int n_noise_seen = 0;
   unsigned mel_mask[14];
   std::vector<double> mel_filters;      // (201, n_mel)
+  // optional in-stream timing of the two kernels (wfe_kernel_timing)
+  bool timing = false;
+  std::vector<hipEvent_t> ev_pool;      // triples: before K1, after K1, after K2
+  size_t ev_used = 0;
   std::string err;
 };
 
@@ -168,8 +172,23 @@ int run_frontend(wfe_context* h, const float* wav, const int64_t* offsets, const
       HIP_TRY(h, wfe::launch_resolve(a, s.count, stream));
     }
     if (mode == 0) HIP_TRY(h, hipMemsetAsync(h->d_clip_max, 0, sizeof(unsigned) * s.count, stream));
+    hipEvent_t* ev = nullptr;
+    if (h->timing) {
+      if (h->ev_used + 3 > h->ev_pool.size()) {
+        for (int i = 0; i < 3; ++i) {
+          hipEvent_t e;
+          HIP_TRY(h, hipEventCreate(&e));
+          h->ev_pool.push_back(e);
+        }
+      }
+      ev = &h->ev_pool[h->ev_used];
+      h->ev_used += 3;
+      HIP_TRY(h, hipEventRecord(ev[0], stream));
+    }
     HIP_TRY(h, wfe::launch_frontend(a, s.count, mode, aug, stream));
+    if (ev) HIP_TRY(h, hipEventRecord(ev[1], stream));
     if (mode == 0) HIP_TRY(h, wfe::launch_clamp(a.out, h->d_clip_max, s.count, per_clip, stream));
+    if (ev) HIP_TRY(h, hipEventRecord(ev[2], stream));
   }
   return WFE_OK;
 }
@@ -235,6 +254,7 @@ int wfe_destroy(wfe_handle h) {
   if (h->d_clip_max) (void)hipFree(h->d_clip_max);
   if (h->d_resolved) (void)hipFree(h->d_resolved);
   if (h->d_noise_meansq) (void)hipFree(h->d_noise_meansq);
+  for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   delete h;
   return WFE_OK;
 }
@@ -244,6 +264,32 @@ const char* wfe_last_error(wfe_handle h) { return h ? h->err.c_str() : g_create_
 int wfe_mel_filters(wfe_handle h, double* host_out) {
   if (!h || !host_out) return fail(h, WFE_ERR_ARG, "null argument");
   std::memcpy(host_out, h->mel_filters.data(), h->mel_filters.size() * sizeof(double));
+  return WFE_OK;
+}
+
+int wfe_kernel_timing(wfe_handle h, int32_t enable) {
+  if (!h) return fail(nullptr, WFE_ERR_ARG, "null handle");
+  h->timing = enable != 0;
+  h->ev_used = 0;
+  return WFE_OK;
+}
+
+int wfe_kernel_times(wfe_handle h, double* frontend_ms, double* clamp_ms, int64_t* launches) {
+  if (!h || !frontend_ms || !clamp_ms || !launches) return fail(h, WFE_ERR_ARG, "null argument");
+  DeviceGuard guard(h->cfg.device);
+  double f = 0.0, c = 0.0;
+  for (size_t i = 0; i + 2 < h->ev_used; i += 3) {
+    HIP_TRY(h, hipEventSynchronize(h->ev_pool[i + 2]));
+    float t1 = 0.f, t2 = 0.f;
+    HIP_TRY(h, hipEventElapsedTime(&t1, h->ev_pool[i], h->ev_pool[i + 1]));
+    HIP_TRY(h, hipEventElapsedTime(&t2, h->ev_pool[i + 1], h->ev_pool[i + 2]));
+    f += t1;
+    c += t2;
+  }
+  *frontend_ms = f;
+  *clamp_ms = c;
+  *launches = (int64_t)(h->ev_used / 3);
+  h->ev_used = 0;
   return WFE_OK;
 }
 

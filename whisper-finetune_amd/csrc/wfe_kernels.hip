@@ -317,7 +317,11 @@ __global__ __launch_bounds__(256) void frontend_kernel(const FrontArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int mel = 16 * mt + 4 * kk + r;
         if (mel < a.n_mel && frame < T) {
-          const float v = log10f(fmaxf(m[mt][r], 1e-10f));     // clamp(min=1e-10).log10()  HF:159
+          // clamp(min=1e-10).log10() (HF:159).  log10 of the float32 floor rounds to
+          // exactly -10; the floor is by far the most common value (silence, padding),
+          // so it is returned exactly rather than through the 1-ulp device log10f.
+          const float pw = m[mt][r];
+          const float v = (pw > 1e-10f) ? log10f(pw) : -10.0f;
           lo[(long long)mel * T + frame] = v;
           wmax = fmaxf(wmax, v);
         }

@@ -1,0 +1,193 @@
+"""Device-side driver of the HIP front end: one ``HipFrontEnd`` per (GPU, n_mel).
+
+torch is used for device memory and streams only; every transform below is a
+call through the C ABI (include/wfe.h) into hand-written gfx950 kernels.  There
+is no CPU path: constructing a ``HipFrontEnd`` without a usable MI355X raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+N_FFT = 400
+HOP = 160
+N_FREQ = 201
+N_SAMPLES = 480000
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class NoiseBank:
+    """Noise clips resident on the device, back to back (the decoded contents of
+    ``CustomDataset.noise_files``, utils/reader.py:75-78,323)."""
+
+    def __init__(self, clips: Sequence[np.ndarray], device: torch.device):
+        self.lengths = [int(len(c)) for c in clips]
+        off = np.zeros(len(clips) + 1, dtype=np.int64)
+        off[1:] = np.cumsum(self.lengths)
+        flat = np.concatenate([np.asarray(c, dtype=np.float32).reshape(-1) for c in clips]) if clips else \
+            np.zeros(0, dtype=np.float32)
+        self.data = torch.from_numpy(flat).to(device)
+        self.offsets = torch.from_numpy(off).to(device)
+        self.n = len(clips)
+
+
+class HipFrontEnd:
+    def __init__(self, n_mel: int = 80, device: int | torch.device | str | None = None,
+                 sampling_rate: int = 16000, n_fft: int = N_FFT, hop_length: int = HOP):
+        self._h = None
+        if not torch.cuda.is_available():
+            raise _lib.WfeError("no MI355X visible to this process: the HIP front end has no CPU fallback")
+        if device is None:
+            device = torch.cuda.current_device()
+        dev = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
+        if dev.type != "cuda":
+            raise _lib.WfeError(f"device {dev} is not a GPU")
+        self.device = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+        self.n_mel = int(n_mel)
+        cfg = _lib.WfeConfig(self.n_mel, int(n_fft), int(hop_length), int(sampling_rate), self.device.index)
+        h = C.c_void_p()
+        _lib.check(_lib.lib().wfe_create(C.byref(cfg), C.byref(h)), None)
+        self._h = h
+
+    def close(self):
+        if self._h is not None:
+            _lib.lib().wfe_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ helpers
+    def mel_filters(self) -> np.ndarray:
+        out = np.zeros((N_FREQ, self.n_mel), dtype=np.float64)
+        _lib.check(_lib.lib().wfe_mel_filters(self._h, out.ctypes.data), self._h)
+        return out
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check_inputs(self, wav, lengths, offsets, batch):
+        for name, t, dt in (("wav", wav, torch.float32), ("lengths", lengths, torch.int32)):
+            if t.device != self.device or t.dtype != dt or not t.is_contiguous():
+                raise ValueError(f"{name} must be a contiguous {dt} tensor on {self.device}")
+        if lengths.numel() != batch:
+            raise ValueError("lengths must have one entry per utterance")
+        if offsets is not None and (offsets.device != self.device or offsets.dtype != torch.int64
+                                    or offsets.numel() != batch):
+            raise ValueError("offsets must be int64[batch] on the device")
+
+    def _geometry(self, wav, lengths, offsets):
+        if offsets is None:
+            if wav.dim() != 2:
+                raise ValueError("wav must be (batch, stride) when offsets is None")
+            return wav.shape[0], wav.shape[1]
+        return lengths.numel(), 0
+
+    def kernel_timing(self, enable: bool) -> None:
+        _lib.check(_lib.lib().wfe_kernel_timing(self._h, 1 if enable else 0), self._h)
+
+    def kernel_times(self):
+        """(frontend_ms, clamp_ms, launches) summed since the last query; synchronises."""
+        f, c, n = C.c_double(), C.c_double(), C.c_int64()
+        _lib.check(_lib.lib().wfe_kernel_times(self._h, C.byref(f), C.byref(c), C.byref(n)), self._h)
+        return f.value, c.value, n.value
+
+    # ---------------------------------------------------------------- hot path
+    def logmel(self, wav: torch.Tensor, lengths: torch.Tensor, n_samples: int = N_SAMPLES,
+               offsets: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """(B, n_mel, n_samples // 160) float32 on the device.  ``wav`` is (B, stride)
+        or, with ``offsets``, a flat buffer of ragged utterances."""
+        batch, stride = self._geometry(wav, lengths, offsets)
+        self._check_inputs(wav, lengths, offsets, batch)
+        shape = (batch, self.n_mel, n_samples // HOP)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() \
+                or out.device != self.device:
+            raise ValueError(f"out must be a contiguous float32 {shape} tensor on {self.device}")
+        _lib.check(_lib.lib().wfe_logmel(self._h, _ptr(wav), _ptr(offsets), _ptr(lengths), stride, batch,
+                                         int(n_samples), _ptr(out), self._stream()), self._h)
+        return out
+
+    def power_spectrum(self, wav: torch.Tensor, lengths: torch.Tensor, n_samples: int = N_SAMPLES,
+                       offsets: Optional[torch.Tensor] = None) -> torch.Tensor:
+        batch, stride = self._geometry(wav, lengths, offsets)
+        self._check_inputs(wav, lengths, offsets, batch)
+        out = torch.empty((batch, N_FREQ, n_samples // HOP), dtype=torch.float32, device=self.device)
+        _lib.check(_lib.lib().wfe_power_spectrum(self._h, _ptr(wav), _ptr(offsets), _ptr(lengths), stride, batch,
+                                                 int(n_samples), _ptr(out), self._stream()), self._h)
+        return out
+
+    # ------------------------------------------------------------ augmentation
+    def _pack_ops(self, plans: Sequence[Sequence[tuple]]):
+        """plans[b] = list of (kind, i0, i1, i2, f0) -> device arrays."""
+        total = sum(len(p) for p in plans)
+        arr = (_lib.WfeAugOp * max(total, 1))()
+        begin = np.zeros(len(plans) + 1, dtype=np.int32)
+        k = 0
+        for b, plan in enumerate(plans):
+            begin[b] = k
+            for (kind, i0, i1, i2, f0) in plan:
+                arr[k] = _lib.WfeAugOp(int(kind), int(i0), int(i1), int(i2), float(f0), 0.0, 0.0)
+                k += 1
+        begin[len(plans)] = k
+        raw = np.frombuffer(arr, dtype=np.uint8).copy()
+        return torch.from_numpy(raw).to(self.device), torch.from_numpy(begin).to(self.device), total
+
+    def augment_logmel(self, wav, lengths, plans, noise: Optional[NoiseBank] = None, n_samples: int = N_SAMPLES,
+                       offsets=None, out=None) -> torch.Tensor:
+        batch, stride = self._geometry(wav, lengths, offsets)
+        self._check_inputs(wav, lengths, offsets, batch)
+        if len(plans) != batch:
+            raise ValueError("one op list per utterance")
+        ops, begin, total = self._pack_ops(plans)
+        shape = (batch, self.n_mel, n_samples // HOP)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        _lib.check(_lib.lib().wfe_augment_logmel(
+            self._h, _ptr(wav), _ptr(offsets), _ptr(lengths), stride, batch, int(n_samples), _ptr(ops), _ptr(begin),
+            total, _ptr(noise.data) if noise else None, _ptr(noise.offsets) if noise else None,
+            noise.n if noise else 0, _ptr(out), self._stream()), self._h)
+        return out
+
+    def augment_waveform(self, wav, lengths, plans, noise: Optional[NoiseBank] = None, n_samples: int = N_SAMPLES,
+                         offsets=None):
+        batch, stride = self._geometry(wav, lengths, offsets)
+        self._check_inputs(wav, lengths, offsets, batch)
+        ops, begin, total = self._pack_ops(plans)
+        out = torch.empty((batch, n_samples), dtype=torch.float32, device=self.device)
+        out_len = torch.empty((batch,), dtype=torch.int32, device=self.device)
+        _lib.check(_lib.lib().wfe_augment_waveform(
+            self._h, _ptr(wav), _ptr(offsets), _ptr(lengths), stride, batch, int(n_samples), _ptr(ops), _ptr(begin),
+            total, _ptr(noise.data) if noise else None, _ptr(noise.offsets) if noise else None,
+            noise.n if noise else 0, _ptr(out), _ptr(out_len), self._stream()), self._h)
+        return out, out_len
+
+
+def pack_ragged(waves: Sequence[np.ndarray], device: torch.device, pinned: bool = False):
+    """Host list of float32 utterances -> (flat device buffer, int64 offsets,
+    int32 lengths).  Each utterance starts on a 16-byte boundary so that the
+    kernel's float4 staging path applies."""
+    lens = np.array([len(w) for w in waves], dtype=np.int64)
+    padded = (lens + 3) // 4 * 4
+    off = np.zeros(len(waves), dtype=np.int64)
+    if len(waves) > 1:
+        off[1:] = np.cumsum(padded)[:-1]
+    total = int(padded.sum()) if len(waves) else 0
+    flat = torch.zeros(max(total, 4), dtype=torch.float32, pin_memory=pinned)
+    fnp = flat.numpy()
+    for o, w in zip(off, waves):
+        fnp[o:o + len(w)] = np.asarray(w, dtype=np.float32).reshape(-1)
+    return (flat.to(device, non_blocking=pinned), torch.from_numpy(off).to(device),
+            torch.from_numpy(lens.astype(np.int32)).to(device))
