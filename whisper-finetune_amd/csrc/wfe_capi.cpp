@@ -27,6 +27,7 @@ struct wfe_context {
   const int64_t* noise_off_seen = nullptr;
   int n_noise_seen = 0;
   unsigned mel_mask[14];
+  int bank = 0;                         // 1: 80-mel, 2: 128-mel compile-time masks, 0: run-time masks
   std::vector<double> mel_filters;      // (201, n_mel)
   // optional in-stream timing of the two kernels (wfe_kernel_timing)
   bool timing = false;
@@ -185,7 +186,7 @@ int run_frontend(wfe_context* h, const float* wav, const int64_t* offsets, const
       h->ev_used += 3;
       HIP_TRY(h, hipEventRecord(ev[0], stream));
     }
-    HIP_TRY(h, wfe::launch_frontend(a, s.count, mode, aug, stream));
+    HIP_TRY(h, wfe::launch_frontend(a, s.count, mode, aug, h->bank, stream));
     if (ev) HIP_TRY(h, hipEventRecord(ev[1], stream));
     if (mode == 0) HIP_TRY(h, wfe::launch_clamp(a.out, h->d_clip_max, s.count, per_clip, stream));
     if (ev) HIP_TRY(h, hipEventRecord(ev[2], stream));
@@ -229,6 +230,8 @@ int wfe_create(const wfe_config* cfg, wfe_handle* out) {
   std::vector<float> dft((size_t)wfe::kDftTableFloats), mel((size_t)wfe::kMelTableFloats);
   wfe_build_dft_table(dft.data());
   wfe_build_mel_table(cfg->n_mel, mel.data(), h->mel_mask);
+  if (cfg->n_mel == 80 && std::memcmp(h->mel_mask, wfe::kMelMask80, sizeof h->mel_mask) == 0) h->bank = 1;
+  if (cfg->n_mel == 128 && std::memcmp(h->mel_mask, wfe::kMelMask128, sizeof h->mel_mask) == 0) h->bank = 2;
 
   DeviceGuard guard(cfg->device);
   hipError_t e = guard.ok ? hipSuccess : hipErrorInvalidDevice;

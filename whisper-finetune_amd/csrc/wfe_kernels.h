@@ -41,7 +41,7 @@ struct FrontArgs {
 };
 
 // mode 0: log10 mel + clip max.  mode 1: power spectrum.
-hipError_t launch_frontend(const FrontArgs& a, int batch, int mode, bool augmented, hipStream_t stream);
+hipError_t launch_frontend(const FrontArgs& a, int batch, int mode, bool augmented, int bank, hipStream_t stream);
 // (x > max-8 ? x : max-8) + 4) / 4 in place over (batch, per_clip)
 hipError_t launch_clamp(float* out, const unsigned* clip_max, int batch, long long per_clip, hipStream_t stream);
 // mean squares of the noise clips (once per noise bank)

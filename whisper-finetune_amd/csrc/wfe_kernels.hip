@@ -140,7 +140,7 @@ __device__ inline int chain_len(const Chain& c, int n_ops_used) {
 }
 
 // ------------------------------------------------------------- kernel 1
-template <int NMT, bool POWER, bool AUG>
+template <int NMT, bool POWER, bool AUG, int BANK>
 __global__ __launch_bounds__(256) void frontend_kernel(const FrontArgs a) {
   __shared__ float lds[kLdsFloats];
   const int tid = threadIdx.x;
@@ -168,24 +168,47 @@ __global__ __launch_bounds__(256) void frontend_kernel(const FrontArgs a) {
     const bool interior = !AUG && i_first >= 0 && i_first + kBlockSamples <= len &&
                           ((reinterpret_cast<uintptr_t>(w + i_first) & 15u) == 0);
     if (interior) {
+      // all 21 loads in flight before the first LDS write: the tile is one HBM
+      // round trip, not 21
       const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(w + i_first);
-      for (int v4 = tid; v4 < kBlockSamples / 4; v4 += 256) {
-        const f32x4 x = src[v4];
-        const int q = 4 * v4;                   // 4 | 160, so the four share q / 160
-        const int base = q + q / kHop;
-        lds[base + 0] = x[0];
-        lds[base + 1] = x[1];
-        lds[base + 2] = x[2];
-        lds[base + 3] = x[3];
+      constexpr int kIters = (kBlockSamples / 4 + 255) / 256;
+      f32x4 buf[kIters];
+#pragma unroll
+      for (int it = 0; it < kIters; ++it) {
+        const int v4 = tid + 256 * it;
+        if (v4 < kBlockSamples / 4) buf[it] = src[v4];
+      }
+#pragma unroll
+      for (int it = 0; it < kIters; ++it) {
+        const int v4 = tid + 256 * it;
+        if (v4 < kBlockSamples / 4) {
+          const int q = 4 * v4;                 // 4 | 160, so the four share q / 160
+          const int base = q + q / kHop;
+          lds[base + 0] = buf[it][0];
+          lds[base + 1] = buf[it][1];
+          lds[base + 2] = buf[it][2];
+          lds[base + 3] = buf[it][3];
+        }
       }
     } else {
-      for (int q = tid; q < kBlockSamples; q += 256) {
-        int i = p0 + q - kHalf;                 // index into the length-n padded utterance
-        if (i < 0) i = -i;                      // torch.stft center=True, pad_mode="reflect"
-        if (i >= n) i = 2 * (n - 1) - i;
-        float v = 0.f;                          // right zero padding (padding_value 0.0)
-        if (i >= 0 && i < len) v = AUG ? chain_eval(c, c.n_ops, i) : w[i];
-        lds[pad_q(q)] = v;
+      constexpr int kBatch = 9;                 // 81 = 9 x 9 positions per thread
+      for (int q0 = tid; q0 < kBlockSamples; q0 += 256 * kBatch) {
+        float vals[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+          const int q = q0 + 256 * u;
+          int i = p0 + q - kHalf;               // index into the length-n padded utterance
+          if (i < 0) i = -i;                    // torch.stft center=True, pad_mode="reflect"
+          if (i >= n) i = 2 * (n - 1) - i;
+          float v = 0.f;                        // right zero padding (padding_value 0.0)
+          if (q < kBlockSamples && i >= 0 && i < len) v = AUG ? chain_eval(c, c.n_ops, i) : w[i];
+          vals[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+          const int q = q0 + 256 * u;
+          if (q < kBlockSamples) lds[pad_q(q)] = vals[u];
+        }
       }
     }
   }
@@ -299,7 +322,7 @@ __global__ __launch_bounds__(256) void frontend_kernel(const FrontArgs a) {
     for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int bt = 0; bt < 7; ++bt) {
-        const unsigned mask = a.mel_mask[f * 7 + bt];
+        const unsigned mask = BANK == 1 ? kMelMask80[f * 7 + bt] : BANK == 2 ? kMelMask128[f * 7 + bt] : a.mel_mask[f * 7 + bt];
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt) {
           if ((mask >> mt) & 1u) {
@@ -452,17 +475,25 @@ __global__ __launch_bounds__(256) void waveform_kernel(const FrontArgs a, float*
 }
 
 // ------------------------------------------------------------- launchers
-template <int NMT, bool POWER, bool AUG>
+template <int NMT, bool POWER, bool AUG, int BANK>
 static hipError_t launch_k1(const FrontArgs& a, int batch, hipStream_t stream) {
   const dim3 grid((a.n_frames + kBlockFrames - 1) / kBlockFrames, batch);
-  hipLaunchKernelGGL((frontend_kernel<NMT, POWER, AUG>), grid, dim3(256), 0, stream, a);
+  hipLaunchKernelGGL((frontend_kernel<NMT, POWER, AUG, BANK>), grid, dim3(256), 0, stream, a);
   return hipGetLastError();
 }
 
-hipError_t launch_frontend(const FrontArgs& a, int batch, int mode, bool aug, hipStream_t stream) {
-  if (mode == 1) return aug ? launch_k1<5, true, true>(a, batch, stream) : launch_k1<5, true, false>(a, batch, stream);
-  if (a.n_mel <= 80) return aug ? launch_k1<5, false, true>(a, batch, stream) : launch_k1<5, false, false>(a, batch, stream);
-  return aug ? launch_k1<8, false, true>(a, batch, stream) : launch_k1<8, false, false>(a, batch, stream);
+// bank: 1 = the 80-mel Whisper bank, 2 = the 128-mel bank (compile-time block
+// masks), 0 = any other feature_size (run-time masks).
+hipError_t launch_frontend(const FrontArgs& a, int batch, int mode, bool aug, int bank, hipStream_t stream) {
+  if (mode == 1)
+    return aug ? launch_k1<5, true, true, 0>(a, batch, stream) : launch_k1<5, true, false, 0>(a, batch, stream);
+  if (bank == 1)
+    return aug ? launch_k1<5, false, true, 1>(a, batch, stream) : launch_k1<5, false, false, 1>(a, batch, stream);
+  if (bank == 2)
+    return aug ? launch_k1<8, false, true, 2>(a, batch, stream) : launch_k1<8, false, false, 2>(a, batch, stream);
+  if (a.n_mel <= 80)
+    return aug ? launch_k1<5, false, true, 0>(a, batch, stream) : launch_k1<5, false, false, 0>(a, batch, stream);
+  return aug ? launch_k1<8, false, true, 0>(a, batch, stream) : launch_k1<8, false, false, 0>(a, batch, stream);
 }
 
 hipError_t launch_clamp(float* out, const unsigned* clip_max, int batch, long long per_clip, hipStream_t stream) {

@@ -43,6 +43,16 @@ constexpr int64_t kDftTableFloats = (int64_t)kSteps * kDftStepFloats;
 constexpr int kMelTiles = 8;
 constexpr int64_t kMelTableFloats = 2LL * kBinTiles * kMelTiles * 64 * 4;
 
+// Non-zero (bin tile, mel tile) blocks of the two standard Whisper banks, bit mt
+// of entry family*7 + bin tile (what wfe_build_mel_table returns in mask14).
+// Known at compile time so that the mel phase of the kernel is straight-line code
+// whose weight loads the compiler can issue ahead of the MFMAs; any other
+// feature_size takes the run-time-mask build.  wfe_create checks them against the
+// masks it computes.
+constexpr unsigned kMelMask80[14] = {0x3, 0x6, 0x4, 0xc, 0x8, 0x8, 0x8, 0x10, 0x10, 0x10, 0x10, 0x10, 0x18, 0x8};
+constexpr unsigned kMelMask128[14] = {0x3, 0xe, 0x18, 0x30, 0x20, 0x60, 0x40,
+                                      0x80, 0x80, 0x80, 0x80, 0xc0, 0x40, 0x40};
+
 // Frames per workgroup: 4 waves x 2 frame tiles x 16 frames.
 constexpr int kWaves = 4;
 constexpr int kFrameTilesPerWave = 2;
