@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Diagnostic: where a wave of kernel 1 spends its cycles.  Loads the stamped
+build (make -C whisper-finetune_amd/csrc stamps), runs one batch and prints the
+median cycles per phase.  Stamps go to a buffer of their own."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "whisper-finetune_amd"))
+from wfe_amd import _lib  # noqa: E402
+
+_lib.LIB_PATH = os.path.join(ROOT, "whisper-finetune_amd", "wfe_amd", "libwfe_hip_stamps.so")
+from wfe_amd.frontend import HipFrontEnd  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+n_mel = int(sys.argv[2]) if len(sys.argv) > 2 else 80
+fe = HipFrontEnd(n_mel=n_mel, device=0)
+lib = _lib.lib()
+lib.wfe_debug_stamps.restype = C.c_int
+lib.wfe_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
+blocks = B * 47
+stamps = torch.zeros((blocks * 4, 8), dtype=torch.int64, device="cuda")
+wav = 0.1 * torch.randn((B, 480000), device="cuda")
+lens = torch.full((B,), 480000, dtype=torch.int32, device="cuda")
+for _ in range(3):
+    fe.logmel(wav, lens)
+torch.cuda.synchronize()
+assert lib.wfe_debug_stamps(fe._h, C.c_void_p(stamps.data_ptr())) == 0
+fe.logmel(wav, lens)
+torch.cuda.synchronize()
+s = stamps.cpu().numpy().astype(np.int64)
+s = s[s[:, 0] != 0]
+names = ["stage(issue+write)", "barrier", "dft k-loop", "butterfly+mel", "log+store+max"]
+d = np.diff(s[:, :6], axis=1)
+print("waves", len(s), "kernel span (cycles)", s[:, 5].max() - s[:, 0].min())
+for i, nme in enumerate(names):
+    print(f"{nme:22s} median {np.median(d[:, i]):9.0f}  p10 {np.percentile(d[:, i], 10):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f}")
+tot = s[:, 5] - s[:, 0]
+print(f"{'total':22s} median {np.median(tot):9.0f}  p10 {np.percentile(tot, 10):9.0f}  p90 {np.percentile(tot, 90):9.0f}")
+
+# co-residency: group waves by (xcc, se/sh/cu, simd) and measure how much of each wave's
+# k-loop overlaps another wave's k-loop on the same SIMD
+hw = s[:, 6] & 0xffffffff
+xcc = s[:, 6] >> 32
+key = (xcc << 16) | (((hw >> 8) & 255) << 4) | ((hw >> 4) & 3)
+print("distinct (xcc,cu,simd):", len(np.unique(key)), " distinct (xcc,cu):", len(np.unique(key >> 4)),
+      " tickets==1:", int((s[:, 7] == 1).sum()) // 4, " ticket max:", int(s[:, 7].max()))
+ov, tot_k = 0, 0
+for k in np.unique(key)[:200]:
+    w = s[key == k]
+    w = w[np.argsort(w[:, 2])]
+    for i in range(len(w)):
+        a0, a1 = w[i, 2], w[i, 3]
+        tot_k += a1 - a0
+        for j in range(len(w)):
+            if j != i:
+                ov += max(0, min(a1, w[j, 3]) - max(a0, w[j, 2]))
+print("fraction of k-loop time overlapped by another k-loop on the same SIMD: %.3f" % (ov / max(tot_k, 1)))

@@ -33,12 +33,14 @@ struct wfe_context {
   bool timing = false;
   std::vector<hipEvent_t> ev_pool;      // triples: before K1, after K1, after K2
   size_t ev_used = 0;
+  unsigned long long* d_stamps = nullptr;   // diagnostic builds only (wfe_debug_stamps)
   std::string err;
 };
 
 namespace {
 
 constexpr int kMaxBatchPerLaunch = 4096;
+constexpr int kCuTickets = 4096;          // per-CU arrival counters behind the clip maxima
 thread_local std::string g_create_err;
 
 int fail(wfe_context* h, int code, const char* fmt, ...) {
@@ -96,6 +98,8 @@ void fill_args(wfe_context* h, wfe::FrontArgs& a, const float* wav, const int64_
   a.mel_tab = h->d_mel;
   std::memcpy(a.mel_mask, h->mel_mask, sizeof a.mel_mask);
   a.clip_max = h->d_clip_max;
+  a.cu_tickets = h->d_clip_max + kMaxBatchPerLaunch;
+  a.stamps = h->d_stamps;
 }
 
 // Batch sliced into launches of at most kMaxBatchPerLaunch utterances.
@@ -172,7 +176,9 @@ int run_frontend(wfe_context* h, const float* wav, const int64_t* offsets, const
       a.resolved = h->d_resolved;
       HIP_TRY(h, wfe::launch_resolve(a, s.count, stream));
     }
-    if (mode == 0) HIP_TRY(h, hipMemsetAsync(h->d_clip_max, 0, sizeof(unsigned) * s.count, stream));
+    // clip maxima of this slice and the per-CU arrival tickets (contiguous): one memset
+    if (mode == 0)
+      HIP_TRY(h, hipMemsetAsync(h->d_clip_max, 0, sizeof(unsigned) * (kMaxBatchPerLaunch + kCuTickets), stream));
     hipEvent_t* ev = nullptr;
     if (h->timing) {
       if (h->ev_used + 3 > h->ev_pool.size()) {
@@ -237,7 +243,7 @@ int wfe_create(const wfe_config* cfg, wfe_handle* out) {
   hipError_t e = guard.ok ? hipSuccess : hipErrorInvalidDevice;
   if (e == hipSuccess) e = hipMalloc(&h->d_dft, dft.size() * sizeof(float));
   if (e == hipSuccess) e = hipMalloc(&h->d_mel, mel.size() * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc(&h->d_clip_max, sizeof(unsigned) * kMaxBatchPerLaunch);
+  if (e == hipSuccess) e = hipMalloc(&h->d_clip_max, sizeof(unsigned) * (kMaxBatchPerLaunch + kCuTickets));
   if (e == hipSuccess) e = hipMemcpy(h->d_dft, dft.data(), dft.size() * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(h->d_mel, mel.data(), mel.size() * sizeof(float), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -269,6 +275,15 @@ int wfe_mel_filters(wfe_handle h, double* host_out) {
   std::memcpy(host_out, h->mel_filters.data(), h->mel_filters.size() * sizeof(double));
   return WFE_OK;
 }
+
+#ifdef WFE_STAMPS
+// Diagnostic library only (not declared in include/wfe.h, not built by default).
+int wfe_debug_stamps(wfe_handle h, unsigned long long* device_buf) {
+  if (!h) return WFE_ERR_ARG;
+  h->d_stamps = device_buf;
+  return WFE_OK;
+}
+#endif
 
 int wfe_kernel_timing(wfe_handle h, int32_t enable) {
   if (!h) return fail(nullptr, WFE_ERR_ARG, "null handle");

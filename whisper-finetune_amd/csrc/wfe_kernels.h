@@ -31,6 +31,7 @@ struct FrontArgs {
   // output
   float* out;                    // (B, n_mel, T) log10 mel power, or (B, 201, T) power
   unsigned* clip_max;            // (B) order-preserving encoding of max log10
+  unsigned* cu_tickets;          // (4096) arrival counters per CU, zeroed with clip_max (stagger heuristic)
   // augmentation (AUG kernels only)
   const wfe_aug_op* ops;
   const int* op_begin;
@@ -38,6 +39,7 @@ struct FrontArgs {
   const long long* noise_off;
   const double* noise_meansq;    // (n_noise) mean square of each noise clip
   Resolved* resolved;            // (total ops) filled by the reduce kernel
+  unsigned long long* stamps;    // diagnostic builds (-DWFE_STAMPS) only: 8 clock stamps per wave
 };
 
 // mode 0: log10 mel + clip max.  mode 1: power spectrum.

@@ -1,20 +1,24 @@
 // wfe_kernels.hip -- gfx950 (MI355X, CDNA4) kernels of the Whisper audio front end.
 //
-// Kernel 1 (frontend_kernel): one workgroup = 128 consecutive frames of one
-// utterance.  The padded-signal span those frames cover (20720 positions) is
-// staged once into LDS -- truncation, zero padding, reflect padding and (AUG
-// builds) the whole augmentation chain are applied while staging, so no padded,
-// augmented or framed copy of the waveform ever exists in HBM.  Each of the 4
-// waves owns 2 tiles of 16 frames and all 101 folded bins: 4 GEMMs (Ce, Se, Co,
-// So; wfe_layout.h) x 7 bin tiles x 2 frame tiles = 56 accumulators of
-// v_mfma_f32_16x16x4_f32, K = 100 in 25 k-steps.  B operands (e = x[n]+x[400-n],
-// o = x[n]-x[400-n]) are built from two ds_read_b32 of the LDS tile; A operands
-// (Hann-windowed twiddles, fp64-built, L2 resident, 200 KB) are fetched one
-// k-step ahead straight into registers as 8 x float4 per lane.  The butterflies
+// Kernel 1 (frontend_kernel): one workgroup = 64 consecutive frames of one
+// utterance, two workgroups resident per CU (2 waves per SIMD) so that one
+// workgroup's staging and epilogue hide under the other's MFMA stream.  The
+// padded-signal span the frames cover (10480 positions) is staged once into LDS
+// -- truncation, zero padding, reflect padding and (AUG builds) the whole
+// augmentation chain are applied while staging, so no padded, augmented or
+// framed copy of the waveform ever exists in HBM.  Each of the 4 waves owns one
+// tile of 16 frames and all 101 folded bins: 4 GEMMs (Ce, Se, Co, So;
+// wfe_layout.h) x 7 bin tiles = 28 accumulators of v_mfma_f32_16x16x4_f32,
+// K = 100 in 25 k-steps.  B operands (e = x[n]+x[400-n], o = x[n]-x[400-n]) are
+// built from two ds_read_b32 of the LDS tile; A operands (Hann-windowed twiddles,
+// fp64-built, L2 resident, 200 KB) are fetched one k-step ahead straight into
+// registers as 8 x float4 per lane (perfectly coalesced 1 KB wave loads, L1/L2
+// hits), so the k-loop has no barrier.  The butterflies
 // Ce+-Co / Se+-So and |.|^2 run on the accumulators, whose C/D layout (frame on
 // the lane, bins in registers) is exactly the B layout the mel MFMA wants, so the
 // power spectrum never leaves registers.  Epilogue: log10, per-wave max ->
-// one atomicMax per wave on the utterance's max word, store.
+// one atomicMax per wave on the utterance's max word; the block's (n_mel x 64)
+// output tile is transposed through LDS and leaves as 256-byte row segments.
 //
 // Kernel 2 (clamp_kernel): max(x, clipmax - 8), (x + 4) / 4, float4 in place.
 //
@@ -27,7 +31,40 @@
 
 namespace wfe {
 
+// Diagnostic build only (make stamps): s_memtime at the phase boundaries of kernel
+// 1, written to a buffer nothing else reads.  The shipped library executes none.
+#ifdef WFE_STAMPS
+#define WFE_STAMP(i)                                                                   \
+  do {                                                                                 \
+    if (a.stamps && lane == 0) {                                                       \
+      unsigned long long t_;                                                           \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
+      a.stamps[((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8 + (i)] = t_; \
+    }                                                                                  \
+  } while (0)
+#else
+#define WFE_STAMP(i) do {} while (0)
+#endif
+
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x3 = __attribute__((ext_vector_type(3))) float;
+
+// The 7 twiddles (one per bin tile) a lane needs per GEMM and k-step.  The table
+// stores 8 (two float4) but the 8th is padding: it is fetched as float4 + float3
+// (global_load_dwordx4 + dwordx3) so that no dead register is the destination of
+// an in-flight load -- hipcc reuses such a register at once and then has to wait
+// for the load (a vmcnt stall right after issue).
+struct Frag7 {
+  f32x4 lo;
+  f32x3 hi;
+  __device__ __forceinline__ float at(int bt) const { return bt < 4 ? lo[bt & 3] : hi[bt & 3]; }
+};
+__device__ __forceinline__ Frag7 load_frag7(const f32x4* p) {
+  Frag7 f;
+  f.lo = p[0];
+  f.hi = *reinterpret_cast<const f32x3*>(p + 64);
+  return f;
+}
 
 // ------------------------------------------------------------------ utilities
 __device__ __forceinline__ unsigned enc_max(float v) {
@@ -141,8 +178,11 @@ __device__ inline int chain_len(const Chain& c, int n_ops_used) {
 
 // ------------------------------------------------------------- kernel 1
 template <int NMT, bool POWER, bool AUG, int BANK>
-__global__ __launch_bounds__(256) void frontend_kernel(const FrontArgs a) {
-  __shared__ float lds[kLdsFloats];
+__global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
+  constexpr bool STAGGER = !POWER;
+  // waveform image | twiddle slots, reused as the output tile after the k-loop
+  constexpr int kAuxFloats = (16 * NMT * kTileStride > 2 * kDftStepFloats) ? 16 * NMT * kTileStride : 2 * kDftStepFloats;
+  __shared__ __attribute__((aligned(16))) float lds[kLdsWaveFloats + kAuxFloats];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -153,8 +193,48 @@ __global__ __launch_bounds__(256) void frontend_kernel(const FrontArgs a) {
   const float* __restrict__ w = a.wav + (a.offsets ? a.offsets[b] : (long long)b * a.row_stride);
   int raw_len = a.lengths[b];
   if (raw_len < 0) raw_len = 0;
+  WFE_STAMP(0);
 
-  // ---- stage the padded-signal span [160 t0, 160 t0 + 20720) into LDS
+  // Stagger (speed only, never correctness).  The two workgroups a CU holds are
+  // dispatched together and, doing identical work, would stage, multiply and
+  // store in lockstep, leaving the matrix pipe idle during both epilogues.  The
+  // second workgroup to ARRIVE on a CU in this launch sleeps about one
+  // non-MFMA phase so that its k-loop runs under its neighbour's staging and
+  // epilogue from then on.  The CU is identified from HW_ID / XCC_ID; a wrong
+  // guess only costs the overlap.
+  if (STAGGER) {
+    if (tid == 0) {
+      const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID
+      const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);      // HW_REG_XCC_ID[3:0]
+      const unsigned key = ((xcc & 15u) << 8) | ((hw >> 8) & 255u);        // xcc | se, sh, cu
+      lds[0] = __uint_as_float(atomicAdd(a.cu_tickets + key, 1u));
+    }
+    __syncthreads();
+    const unsigned ticket = __float_as_uint(lds[0]);
+    __syncthreads();
+#ifdef WFE_STAMPS
+    if (a.stamps && lane == 0) {
+      const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+      const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+      unsigned long long* st = a.stamps + ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+      st[6] = ((unsigned long long)xcc << 32) | hw;
+      st[7] = ticket;
+    }
+#endif
+    if (ticket == 1u) {
+      __builtin_amdgcn_s_sleep(127);
+      __builtin_amdgcn_s_sleep(127);
+      __builtin_amdgcn_s_sleep(127);
+    }
+  }
+
+  // k-steps 0 and 1 of the twiddle table (8 KB each): in flight while the
+  // waveform is staged, then parked in the two LDS slots
+  const f32x4* __restrict__ gtab = reinterpret_cast<const f32x4*>(a.dft_tab) + tid;
+  f32x4* const slots = reinterpret_cast<f32x4*>(lds + kLdsWaveFloats);       // 2 x 512 float4
+  f32x4 g0 = gtab[0], g1 = gtab[256], g2 = gtab[512], g3 = gtab[768];
+
+  // ---- stage the padded-signal span [160 t0, 160 t0 + 10480) into LDS
   {
     Chain c;
     int len = raw_len;
@@ -168,8 +248,7 @@ __global__ __launch_bounds__(256) void frontend_kernel(const FrontArgs a) {
     const bool interior = !AUG && i_first >= 0 && i_first + kBlockSamples <= len &&
                           ((reinterpret_cast<uintptr_t>(w + i_first) & 15u) == 0);
     if (interior) {
-      // all 21 loads in flight before the first LDS write: the tile is one HBM
-      // round trip, not 21
+      // every load in flight before the first LDS write: one HBM round trip per tile
       const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(w + i_first);
       constexpr int kIters = (kBlockSamples / 4 + 255) / 256;
       f32x4 buf[kIters];
@@ -191,7 +270,7 @@ __global__ __launch_bounds__(256) void frontend_kernel(const FrontArgs a) {
         }
       }
     } else {
-      constexpr int kBatch = 9;                 // 81 = 9 x 9 positions per thread
+      constexpr int kBatch = 7;                 // 41 positions per thread in 6 batches of 7
       for (int q0 = tid; q0 < kBlockSamples; q0 += 256 * kBatch) {
         float vals[kBatch];
 #pragma unroll
@@ -212,147 +291,234 @@ __global__ __launch_bounds__(256) void frontend_kernel(const FrontArgs a) {
       }
     }
   }
+  slots[tid] = g0;
+  slots[256 + tid] = g1;
+  slots[512 + tid] = g2;
+  slots[768 + tid] = g3;
+  WFE_STAMP(1);
   __syncthreads();
+  WFE_STAMP(2);
 
   // ---- folded DFT as 4 GEMMs on v_mfma_f32_16x16x4_f32
   const int jl = lane & 15;
   const int kk = lane >> 4;
   const int d_lo = 2 * (kk >> 1) + 16 * (kk & 1);
   const int d_hi = 2 * kk;
-  int rowbase[2];
-#pragma unroll
-  for (int ft = 0; ft < 2; ++ft) rowbase[ft] = 161 * ((wave * 2 + ft) * 16 + jl);
+  const int rowbase = 161 * (wave * 16 + jl);          // pad_q(160 * frame-in-block)
 
-  f32x4 acc[2][4][7];
-#pragma unroll
-  for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int bt = 0; bt < 7; ++bt) acc[ft][g][bt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const f32x4* __restrict__ tab = reinterpret_cast<const f32x4*>(a.dft_tab) + lane;
-  f32x4 A[4][2];
+  f32x4 acc[4][7];
 #pragma unroll
   for (int g = 0; g < 4; ++g)
 #pragma unroll
-    for (int h = 0; h < 2; ++h) A[g][h] = tab[(g * 2 + h) * 64];
+    for (int bt = 0; bt < 7; ++bt) acc[g][bt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 1
-  for (int s = 0; s < kSteps; ++s) {
-    // next step's twiddles, one step ahead (the reload at s = 24 is harmless)
-    const int sn = (s + 1 < kSteps) ? s + 1 : s;
-    f32x4 An[4][2];
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) An[g][h] = tab[((sn * 4 + g) * 2 + h) * 64];
-
-    const int nb = (s < 24) ? (32 * (s >> 2) + 4 * (s & 3) + d_lo) : (192 + d_hi);
-    float e[2][2], o[2][2];
+  // The k-loop, fully unrolled (25 steps) so that every step-dependent index is a
+  // compile-time constant and the LDS addresses are lane base + immediate.  The
+  // twiddles of one k-step (8 KB) are shared by the 4 waves through a
+  // double-buffered LDS slot, so the CU's L1/TA path carries each of them once per
+  // workgroup instead of once per wave.  Everything a step consumes was requested
+  // a whole step earlier, and the requests are dealt out between the MFMAs of the
+  // step in four small batches so that the matrix pipe never waits on their issue:
+  //   step s:  MFMA 1       | global->reg A(s+2) (32 B/thread), LDS->reg fragments g=0 of A(s+1)
+  //            MFMA 2..7    | LDS->reg fragments g=1, samples of step s+1
+  //            MFMA 8..14   | fragments g=2
+  //            MFMA 15..21  | fragments g=3
+  //            MFMA 22..28  | reg->LDS A(s+2) into slot s&1 (read out in step s-1) | barrier
+  // What keeps hipcc from serialising this (checked in the .s): the two fragment
+  // register sets ping-pong (a single set plus a copy gets the copy, and its wait,
+  // hoisted to a few MFMAs after the reads); scheduling barriers pin each batch
+  // (otherwise requests sink to their first use); the 8th, padding, twiddle is never
+  // read (a dead destination register is reused at once and forces a wait).
+  float xf[2], xb[2];
+  const int lane_lo = rowbase + d_lo, lane_hi = rowbase + d_hi;
+  auto sample_request = [&](int s) {
+    // n = dft_n_of(c, s, kk) = nb + delta(lane) + c0, c0 = 2 (even class) or 1 (odd)
+    const bool tail = s == kSteps - 1;
+    const int nb = tail ? 192 : (32 * (s >> 2) + 4 * (s & 3));
+    const int dl = tail ? d_hi : d_lo;
+    const int base = tail ? lane_hi : lane_lo;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      const int nn = nb + (c ? 1 : 2);                 // dft_n_of(c, s, kk), 1..200
+      const int nn = nb + dl + (c ? 1 : 2);            // 1..200
       const int mm = kNfft - nn;                       // 200..399
-      const int off_f = nn + (nn >= kHop ? 1 : 0);
-      const int off_b = mm + 1 + (mm >= 2 * kHop ? 1 : 0);
-#pragma unroll
-      for (int ft = 0; ft < 2; ++ft) {
-        const float xf = lds[rowbase[ft] + off_f];
-        const float xb = lds[rowbase[ft] + off_b];
-        e[ft][c] = xf + xb;
-        o[ft][c] = xf - xb;
-      }
+      // pad_q(160 j + x) = 161 j + x + x / 160; the x / 160 term is a compile-time
+      // constant except in the few steps whose 4 k-lanes straddle 160 or 320
+      xf[c] = lds[base + nb + (c ? 1 : 2) + (nn >= kHop ? 1 : 0)];
+      xb[c] = lds[2 * rowbase - base + kNfft - nb - (c ? 1 : 2) + 1 + (mm >= 2 * kHop ? 1 : 0)];
     }
+  };
+  Frag7 Ra[4], Rb[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
+  for (int g = 0; g < 4; ++g) Ra[g] = load_frag7(slots + lane + g * 128);
+  sample_request(0);
+#pragma unroll
+  for (int s = 0; s < kSteps; ++s) {
+    Frag7(&Rc)[4] = (s & 1) ? Rb : Ra;
+    Frag7(&Rn)[4] = (s & 1) ? Ra : Rb;
+    const bool next = s + 1 < kSteps, stage = s + 2 < kSteps;
+    const f32x4* nslot = slots + ((s + 1) & 1) * 512 + lane;
+    float e[2], o[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      e[c] = xf[c] + xb[c];
+      o[c] = xf[c] - xb[c];
+    }
+    auto mfma = [&](int g, int bt) {
+      acc[g][bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rc[g].at(bt), (g & 1) ? o[g >> 1] : e[g >> 1], acc[g][bt],
+                                                        0, 0, 0);
+    };
+    mfma(0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (stage) {
+      g0 = gtab[(s + 2) * 512];
+      g1 = gtab[(s + 2) * 512 + 256];
+    }
+    if (next) Rn[0] = load_frag7(nslot);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int bt = 1; bt < 7; ++bt) mfma(0, bt);
+    __builtin_amdgcn_sched_barrier(0);
+    if (next) {
+      Rn[1] = load_frag7(nslot + 128);
+      sample_request(s + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int bt = 0; bt < 7; ++bt) mfma(1, bt);
+    __builtin_amdgcn_sched_barrier(0);
+    if (next) Rn[2] = load_frag7(nslot + 256);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int bt = 0; bt < 7; ++bt) mfma(2, bt);
+    __builtin_amdgcn_sched_barrier(0);
+    if (next) Rn[3] = load_frag7(nslot + 384);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int bt = 0; bt < 7; ++bt) mfma(3, bt);
+    __builtin_amdgcn_sched_barrier(0);
+    if (stage) {
+      slots[(s & 1) * 512 + tid] = g0;
+      slots[(s & 1) * 512 + 256 + tid] = g1;
+    }
+    if (next) __syncthreads();
+  }
+
+  WFE_STAMP(3);
+  // Mel weight fragments of every live (bin tile, mel tile) block: all requested
+  // here, ahead of the butterflies, so that the mel phase pays one L2 round trip
+  // instead of one per block (the scheduling barrier pins the batch).
+  const f32x4* __restrict__ mtab = reinterpret_cast<const f32x4*>(a.mel_tab) + lane;
+  f32x4 wv[2][7][NMT];
+  if (!POWER && BANK != 0) {
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int bt = 0; bt < 7; ++bt)
 #pragma unroll
-        for (int ft = 0; ft < 2; ++ft)
-          acc[ft][g][bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-              A[g][bt >> 2][bt & 3], (g & 1) ? o[ft][g >> 1] : e[ft][g >> 1], acc[ft][g][bt], 0, 0, 0);
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-#pragma unroll
-      for (int h = 0; h < 2; ++h) A[g][h] = An[g][h];
+        for (int mt = 0; mt < NMT; ++mt)
+          if (((BANK == 1 ? kMelMask80[f * 7 + bt] : kMelMask128[f * 7 + bt]) >> mt) & 1u)
+            wv[f][bt][mt] = mtab[((f * 7 + bt) * kMelTiles + mt) * 64];
+    __builtin_amdgcn_sched_barrier(0);
   }
-
   // ---- butterflies + power: family 0 = bin k, family 1 = bin 200 - k
-  f32x4 P[2][2][7];
+  f32x4 P[2][7];
 #pragma unroll
-  for (int ft = 0; ft < 2; ++ft)
-#pragma unroll
-    for (int bt = 0; bt < 7; ++bt) {
-      const f32x4 ce = acc[ft][0][bt], se = acc[ft][1][bt], co = acc[ft][2][bt], so = acc[ft][3][bt];
-      const f32x4 rp = ce + co, ip = se + so, rm = ce - co, im = se - so;
-      P[ft][0][bt] = rp * rp + ip * ip;
-      P[ft][1][bt] = rm * rm + im * im;
-    }
+  for (int bt = 0; bt < 7; ++bt) {
+    const f32x4 ce = acc[0][bt], se = acc[1][bt], co = acc[2][bt], so = acc[3][bt];
+    const f32x4 rp = ce + co, ip = se + so, rm = ce - co, im = se - so;
+    P[0][bt] = rp * rp + ip * ip;
+    P[1][bt] = rm * rm + im * im;
+  }
+  const int frame = t0 + wave * 16 + jl;
 
   if (POWER) {
     float* __restrict__ po = a.out + (long long)b * kNfreq * T;
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft) {
-      const int frame = t0 + (wave * 2 + ft) * 16 + jl;
+    for (int bt = 0; bt < 7; ++bt)
 #pragma unroll
-      for (int bt = 0; bt < 7; ++bt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int k = 16 * bt + 4 * kk + r;
-          if (frame < T && k < kFoldBins) {
-            po[(long long)k * T + frame] = P[ft][0][bt][r];
-            if (k < kFoldBins - 1) po[(long long)(200 - k) * T + frame] = P[ft][1][bt][r];
-          }
+      for (int r = 0; r < 4; ++r) {
+        const int k = 16 * bt + 4 * kk + r;
+        if (frame < T && k < kFoldBins) {
+          po[(long long)k * T + frame] = P[0][bt][r];
+          if (k < kFoldBins - 1) po[(long long)(200 - k) * T + frame] = P[1][bt][r];
         }
-    }
+      }
     return;
   }
 
   // ---- mel projection on the same MFMA; all-zero (bin tile, mel tile) blocks skipped
-  const f32x4* __restrict__ mtab = reinterpret_cast<const f32x4*>(a.mel_tab) + lane;
-  float* __restrict__ lo = a.out + (long long)b * a.n_mel * T;
-  float wmax = -INFINITY;
+  f32x4 m[NMT];
 #pragma unroll
-  for (int ft = 0; ft < 2; ++ft) {
-    f32x4 m[NMT];
+  for (int mt = 0; mt < NMT; ++mt) m[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (BANK != 0) {
 #pragma unroll
-    for (int mt = 0; mt < NMT; ++mt) m[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int bt = 0; bt < 7; ++bt)
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+          if (((BANK == 1 ? kMelMask80[f * 7 + bt] : kMelMask128[f * 7 + bt]) >> mt) & 1u) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              m[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[f][bt][mt][r], P[f][bt][r], m[mt], 0, 0, 0);
+          }
+  } else {
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
       for (int bt = 0; bt < 7; ++bt) {
-        const unsigned mask = BANK == 1 ? kMelMask80[f * 7 + bt] : BANK == 2 ? kMelMask128[f * 7 + bt] : a.mel_mask[f * 7 + bt];
+        const unsigned mask = a.mel_mask[f * 7 + bt];
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt) {
           if ((mask >> mt) & 1u) {
-            const f32x4 wv = mtab[((f * 7 + bt) * kMelTiles + mt) * 64];
+            const f32x4 w4 = mtab[((f * 7 + bt) * kMelTiles + mt) * 64];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-              m[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[r], P[ft][f][bt][r], m[mt], 0, 0, 0);
+              m[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[r], P[f][bt][r], m[mt], 0, 0, 0);
           }
         }
       }
-    const int frame = t0 + (wave * 2 + ft) * 16 + jl;
-#pragma unroll
-    for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int mel = 16 * mt + 4 * kk + r;
-        if (mel < a.n_mel && frame < T) {
-          // clamp(min=1e-10).log10() (HF:159).  log10 of the float32 floor rounds to
-          // exactly -10; the floor is by far the most common value (silence, padding),
-          // so it is returned exactly rather than through the 1-ulp device log10f.
-          const float pw = m[mt][r];
-          const float v = (pw > 1e-10f) ? log10f(pw) : -10.0f;
-          lo[(long long)mel * T + frame] = v;
-          wmax = fmaxf(wmax, v);
-        }
-      }
   }
+  WFE_STAMP(4);
+
+  // ---- log10, utterance max, and the block's (n_mel x 64 frames) tile through LDS
+  // so that every mel row leaves as one 256-byte run of float4 stores.
+  // clamp(min=1e-10).log10() (HF:159): log10 of the float32 floor rounds to exactly
+  // -10 and the floor is by far the most common value (silence, padding), so it is
+  // produced exactly; above it v_log_f32 * log10(2) is within 1.2e-6 of log10.
+  float* const tile = lds + kLdsWaveFloats;            // [16 * NMT][kTileStride]
+  float wmax = -INFINITY;
+  const bool frame_ok = frame < T;
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int mel = 16 * mt + 4 * kk + r;
+      const float pw = m[mt][r];
+      const float v = (pw > 1e-10f) ? __builtin_amdgcn_logf(pw) * 0.30102999566398120f : -10.0f;
+      tile[mel * kTileStride + wave * 16 + jl] = v;
+      if (frame_ok && mel < a.n_mel) wmax = fmaxf(wmax, v);
+    }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, d, 64));
   if (lane == 0 && wmax > -INFINITY) atomicMax(a.clip_max + b, enc_max(wmax));
+  __syncthreads();
+  float* __restrict__ lo = a.out + (long long)b * a.n_mel * T + t0;
+  const int frames_here = (T - t0 < kBlockFrames) ? (T - t0) : kBlockFrames;
+  if ((T & 3) == 0 && (reinterpret_cast<uintptr_t>(lo) & 15u) == 0) {
+    for (int idx = tid; idx < a.n_mel * (kBlockFrames / 4); idx += 256) {
+      const int mel = idx >> 4, c4 = idx & 15;
+      if (4 * c4 < frames_here)                         // T % 4 == 0: a float4 is all-valid or all-out
+        *reinterpret_cast<f32x4*>(lo + (long long)mel * T + 4 * c4) =
+            *reinterpret_cast<const f32x4*>(tile + mel * kTileStride + 4 * c4);
+    }
+  } else {
+    for (int idx = tid; idx < a.n_mel * kBlockFrames; idx += 256) {
+      const int mel = idx >> 6, fb = idx & 63;
+      if (fb < frames_here) lo[(long long)mel * T + fb] = tile[mel * kTileStride + fb];
+    }
+  }
+  WFE_STAMP(5);
 }
 
 // ------------------------------------------------------------- kernel 2

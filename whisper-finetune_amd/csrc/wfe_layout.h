@@ -53,17 +53,22 @@ constexpr unsigned kMelMask80[14] = {0x3, 0x6, 0x4, 0xc, 0x8, 0x8, 0x8, 0x10, 0x
 constexpr unsigned kMelMask128[14] = {0x3, 0xe, 0x18, 0x30, 0x20, 0x60, 0x40,
                                       0x80, 0x80, 0x80, 0x80, 0xc0, 0x40, 0x40};
 
-// Frames per workgroup: 4 waves x 2 frame tiles x 16 frames.
+// Frames per workgroup: 4 waves x 1 frame tile x 16 frames.  Two workgroups are
+// resident per CU (2 waves per SIMD, <= 256 registers each), so one workgroup's
+// staging / epilogue overlaps the other's MFMA stream.
 constexpr int kWaves = 4;
-constexpr int kFrameTilesPerWave = 2;
-constexpr int kBlockFrames = kWaves * kFrameTilesPerWave * 16;     // 128
-constexpr int kBlockSamples = (kBlockFrames - 1) * kHop + kNfft;   // 20720 padded-signal positions
+constexpr int kBlockFrames = kWaves * 16;                           // 64
+constexpr int kBlockSamples = (kBlockFrames - 1) * kHop + kNfft;   // 10480 padded-signal positions
 
 // LDS image of the waveform tile: position q -> q + q/160.  The extra word per
 // hop makes the 16 frames of an MFMA B operand (stride 160 = 0 mod 32 banks)
 // land on 16 consecutive banks.
 WFE_HD int pad_q(int q) { return q + q / kHop; }
-constexpr int kLdsFloats = kBlockSamples - 1 + (kBlockSamples - 1) / kHop + 1;   // 20849
+constexpr int kLdsWaveFloats = ((kBlockSamples - 1 + (kBlockSamples - 1) / kHop + 1) + 3) / 4 * 4;   // 10548
+// The output tile [mel][64 frames] that follows it in LDS: 4 extra words per row
+// keep rows 16-byte aligned and put the 4 mel rows of one MFMA register on
+// disjoint bank halves.
+constexpr int kTileStride = kBlockFrames + 4;
 
 // n handled by k-lane kk (0..3) of k-step s (0..24) for parity class c
 // (0: even n, 1: odd n).  Within lanes 0..31 (kk 0,1) and 32..63 (kk 2,3) the two
