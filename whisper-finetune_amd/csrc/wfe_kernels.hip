@@ -471,7 +471,9 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt) {
           if ((mask >> mt) & 1u) {
-            const f32x4 w4 = mtab[((f * 7 + bt) * kMelTiles + mt) * 64];
+            // uniform base + 32-bit lane offset: keeps the address in SGPRs (one VGPR
+            // pair per block would spill in this run-time-mask build)
+            const f32x4 w4 = reinterpret_cast<const f32x4*>(a.mel_tab)[((f * 7 + bt) * kMelTiles + mt) * 64 + lane];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
               m[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[r], P[f][bt][r], m[mt], 0, 0, 0);

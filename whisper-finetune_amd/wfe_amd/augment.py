@@ -1,0 +1,84 @@
+"""Host side of the augmentation chain: draws the random decisions exactly as
+``CustomDataset.augment`` does (/root/reference/utils/reader.py:246-278 -- same
+``random`` calls in the same order, so a seeded run replays the reference's
+choices) and turns them into the per-utterance op list the HIP kernels apply
+while staging the waveform (include/wfe.h ``wfe_aug_op``).  No sample is touched
+on the host.
+
+Draw order restated from the reference:
+  * config entries in file order; an entry whose ``type`` is one of speed / shift /
+    volume / resample / noise / reverb draws ``random.random()`` once (also at
+    prob 0.0); any other type (e.g. specaug) draws nothing here;
+  * speed:  ``random.choice(np.linspace(min, max, num))``; rate 1.0 is a no-op;
+  * shift:  ``random.randint(min_ms, max_ms)``; samples = int(ms * sr / 1000);
+  * volume: ``random.randint(min_dB, max_dB)``; multiplier float32(10 ** (g / 20));
+  * noise:  only when noise clips exist: ``random.choice(files)``,
+            ``random.randint(min_snr, max_snr)`` and, when the clip is longer than
+            the sample, ``random.randint(0, len_noise - len_sample)`` (reader.py:337);
+  * resample / reverb: gate drawn; firing raises NotImplementedError (SURVEY 8f N1/N2:
+    not part of the GPU chain yet) -- with the shipped config (resample prob 0.0,
+    placeholder rir_dir) neither can fire.
+"""
+from __future__ import annotations
+
+import random as _random
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from ._lib import AUG_NOISE, AUG_SHIFT, AUG_SPEED, AUG_VOLUME
+
+Op = Tuple[int, int, int, int, float]      # (kind, i0, i1, i2, f0) -- see wfe_aug_op
+
+
+class AugmentPlanner:
+    def __init__(self, configs: Sequence[dict], noise_lengths: Optional[Sequence[int]] = None,
+                 n_rir_files: int = 0):
+        self.configs = list(configs)
+        self.noise_lengths = list(noise_lengths) if noise_lengths else []
+        self.n_rir_files = int(n_rir_files)
+        self.speed_rates = None            # lazily built, like CustomDataset.speed_rates (reader.py:249-252)
+
+    def draw(self, length: int, sample_rate: int, rnd=_random) -> Tuple[List[Op], int]:
+        """Decisions for one utterance of ``length`` samples -> (ops, final length)."""
+        ops: List[Op] = []
+        n = int(length)
+        for cfg in self.configs:
+            kind, prob, prm = cfg["type"], cfg.get("prob"), cfg.get("params", {})
+            if kind == "speed" and rnd.random() < prob:
+                if self.speed_rates is None:
+                    self.speed_rates = np.linspace(prm["min_speed_rate"], prm["max_speed_rate"],
+                                                   prm["num_rates"], endpoint=True)
+                rate = rnd.choice(self.speed_rates)
+                if rate != 1.0:
+                    if rate <= 0:
+                        raise ValueError("speed rate must be > 0")
+                    if any(o[0] == AUG_SPEED for o in ops):
+                        raise NotImplementedError("more than one speed op per utterance")
+                    new_len = int(n / rate)
+                    ops.append((AUG_SPEED, new_len, 0, 0, 0.0))
+                    n = new_len
+            if kind == "shift" and rnd.random() < prob:
+                ms = rnd.randint(prm["min_shift_ms"], prm["max_shift_ms"])
+                if abs(ms) / 1000.0 > n / sample_rate:
+                    raise ValueError("|shift_ms| exceeds the clip duration")
+                k = int(ms * sample_rate / 1000)
+                if k != 0:
+                    ops.append((AUG_SHIFT, k, 0, 0, 0.0))
+            if kind == "volume" and rnd.random() < prob:
+                gain = rnd.randint(prm["min_gain_dBFS"], prm["max_gain_dBFS"])
+                ops.append((AUG_VOLUME, 0, 0, gain, float(np.float32(10. ** (gain / 20.)))))
+            if kind == "resample" and rnd.random() < prob:
+                raise NotImplementedError("resample augmentation is not part of the GPU chain yet (SURVEY 8f N2)")
+            if kind == "noise" and rnd.random() < prob:
+                if self.noise_lengths:
+                    j = rnd.choice(range(len(self.noise_lengths)))
+                    snr = rnd.randint(prm["min_snr_dB"], prm["max_snr_dB"])
+                    ln = self.noise_lengths[j]
+                    start = rnd.randint(0, ln - n) if ln > n else 0
+                    ops.append((AUG_NOISE, j, start, snr, 0.0))
+            if kind == "reverb" and rnd.random() < prob:
+                if self.n_rir_files > 0:
+                    rnd.choice(range(self.n_rir_files))
+                    raise NotImplementedError("reverb augmentation is not part of the GPU chain yet (SURVEY 8f N1)")
+        return ops, n
