@@ -1,0 +1,458 @@
+"""Dataset and collators of the GPU front end: the callers on either side of the
+log-mel path, under the reference's names.
+
+``CustomDataset`` keeps the constructor and item contract of
+/root/reference/utils/reader.py:17-216 with one structural change forced by the
+hardware: a DataLoader worker is a forked process and cannot touch the GPU, so
+``__getitem__`` stops at the DECODED WAVEFORM plus the DRAWN augmentation plan
+(same ``random`` calls in the same order as reader.py:246-278, see augment.py) and
+the labels.  The collator, running in the rank's main process, stages the whole
+batch ragged and produces ``input_features`` with ONE fused launch
+(augment -> pad/trim -> STFT -> mel -> log -> clamp).
+
+``DataCollatorSpeechSeq2SeqWithPadding`` / ``...forEval``: the reference ships no
+source for these (its utils/data_utils.py is a byte copy of evaluation.py), so
+they are written from the call-site contract -- PARITY UNPINNED:
+  * constructed as ``Collator(processor=processor)``        finetune.py:70, evaluation.py:63
+  * called by the DataLoader on ``list[dict]`` from ``CustomDataset``
+  * records with ``input_features is None`` are dropped      reader.py:209-216
+  * per-item features may be ``np.ndarray (1, M, 3000)`` or a ``torch.Tensor`` (after specaug)
+  * returns ``input_features`` float32 (B, M, T) and ``labels`` int64 (B, L) padded with -100
+                                                            evaluation.py:110-111, finetune.py:131-132
+  * the eval variant also returns ``id`` and keeps the 4 prompt tokens
+                                                            evaluation.py:94-99,106,131
+"""
+from __future__ import annotations
+
+import json
+import mmap
+import os
+import random
+import sys
+import wave
+from typing import Any, List, Optional
+
+import numpy as np
+import torch
+
+from .augment import AugmentPlanner
+
+try:                                    # audio decode is host I/O, outside the GPU path
+    import soundfile as _sf
+except Exception:                       # noqa: BLE001
+    _sf = None
+
+
+# decoded noise clips of the dataset that was built on a processor: the collator is
+# constructed from the processor alone (finetune.py:70) and finds them here
+_NOISE_CLIPS: dict = {}
+
+
+# ------------------------------------------------------------------ audio decode
+def read_audio(path: str, start: Optional[float] = None, end: Optional[float] = None):
+    """``soundfile.read(path, dtype='float32')`` (reader.py:144) or the sliced read of
+    ``slice_from_file`` (reader.py:222-243: times rounded to 3 decimals, negative
+    times count from the end, frames = int(t * sr)).  Falls back to the stdlib
+    ``wave`` module for 16-bit PCM when soundfile is not installed."""
+    if _sf is not None:
+        if start is None:
+            data, sr = _sf.read(path, dtype="float32")
+            return data, sr
+        f = _sf.SoundFile(path)
+        sr, total = f.samplerate, len(f)
+        s, e = _slice_frames(start, end, total, sr)
+        f.seek(s)
+        return f.read(frames=e - s, dtype="float32"), sr
+    with wave.open(path) as w:
+        if w.getsampwidth() != 2:
+            raise ValueError("without soundfile only 16-bit PCM WAV can be decoded")
+        sr, total, ch = w.getframerate(), w.getnframes(), w.getnchannels()
+        s, e = (0, total) if start is None else _slice_frames(start, end, total, sr)
+        w.setpos(s)
+        pcm = np.frombuffer(w.readframes(e - s), dtype="<i2").astype(np.float32) / 32768.0
+    return (pcm.reshape(-1, ch) if ch > 1 else pcm), sr
+
+
+def _slice_frames(start, end, total, sr):
+    duration = round(float(total) / sr, 3)
+    start, end = round(start, 3), round(end, 3)
+    if start < 0.0:
+        start += duration
+    if end < 0.0:
+        end += duration
+    start = max(start, 0.0)
+    end = min(end, duration)
+    if end < 0.0:
+        raise ValueError("slice end (%f s) out of range" % end)
+    if start > end:
+        raise ValueError("slice start (%f s) is after its end (%f s)" % (start, end))
+    return int(start * sr), int(end * sr)
+
+
+# ------------------------------------------------------------------ manifests
+class _BinaryManifest:
+    """Reader of the reference's ``.header`` / ``.data`` pair (utils/binary.py:38-72):
+    header lines ``key\\toffset\\tlength``; the payload is one JSON object."""
+
+    def __init__(self, header_path, min_duration, max_duration):
+        self.fp = open(header_path.replace(".header", ".data"), "rb")
+        self.m = mmap.mmap(self.fp.fileno(), 0, access=mmap.ACCESS_READ)
+        self.keys, self.where = [], {}
+        with open(header_path, "rb") as f:
+            for line in f:
+                key, pos, ln = line.split(b"\t")
+                rec = json.loads(self.m[int(pos):int(pos) + int(ln)].decode("utf-8"))
+                if rec["duration"] < min_duration:
+                    continue
+                if max_duration != -1 and rec["duration"] > max_duration:
+                    continue
+                self.keys.append(key)
+                self.where[key] = (int(pos), int(ln))
+
+    def get(self, key):
+        pos, ln = self.where[key]
+        return json.loads(self.m[pos:pos + ln].decode("utf-8"))
+
+
+# ------------------------------------------------------------------ dataset
+class CustomDataset(torch.utils.data.Dataset):
+    """Same constructor as reader.py:18-27.  Items are
+    ``{"waveform": float32 (N,), "aug_ops": [...], "labels": list[int], "id": str}``
+    (or the reference's null record ``{"input_features": None, "labels": None,
+    "id": "error_<idx>"}`` when anything raises, reader.py:209-216)."""
+
+    def __init__(self, data_list_path, processor, mono=True, language=None, timestamps=False, sample_rate=16000,
+                 min_duration=0.5, max_duration=30, augment_config_path=None):
+        super().__init__()
+        assert min_duration >= 0.5, f"min_duration must be >= 0.5, got {min_duration}"
+        assert max_duration <= 30, f"max_duration must be <= 30, got {max_duration}"
+        self.data_list_path = data_list_path
+        self.processor = processor
+        self.sample_rate = sample_rate
+        self.mono = mono
+        self.language = language
+        self.timestamps = timestamps
+        self.min_duration = min_duration
+        self.max_duration = max_duration
+        self.vocab = self.processor.tokenizer.get_vocab()
+        self.timestamp_begin = self.vocab["<|notimestamps|>"] + 1
+        self.startoftranscript = self.vocab["<|startoftranscript|>"]
+        self.endoftext = self.vocab["<|endoftext|>"]
+        self.nocaptions = self.vocab["<|nocaptions|>"] if "<|nocaptions|>" in self.vocab else self.vocab["<|nospeech|>"]
+        self._load_data_list()
+        self._decoded: dict = {}
+        self._pool = None
+        self._pool_size = int(os.environ.get("WFE_DECODE_THREADS", "8"))
+        self.augment_configs = None
+        self.spec_aug = None
+        self.noise_files: Optional[List[str]] = None
+        self.rir_files: Optional[List[str]] = None
+        self.noise_clips: List[np.ndarray] = []     # decoded once, uploaded by the collator
+        self.planner: Optional[AugmentPlanner] = None
+        if augment_config_path:
+            with open(augment_config_path, "r", encoding="utf-8") as f:
+                self.augment_configs = json.load(f)
+            self.spec_aug = dict()
+            for cfg in self.augment_configs:
+                if cfg.get("type") == "noise":
+                    d = cfg["params"].get("noise_dir", None)
+                    if d:
+                        self.noise_files = self._load_wav_files(d)
+                    else:
+                        print("Warning: 'noise_dir' is not specified in the configuration.")
+                if cfg.get("type") == "reverb":
+                    d = cfg["params"].get("rir_dir", None)
+                    if d:
+                        self.rir_files = self._load_wav_files(d)
+                    else:
+                        print("Warning: 'rir_dir' is not specified in the configuration.")
+                if cfg.get("type") == "specaug":
+                    params = cfg.get("params", {})
+                    defaults = {"num_t_mask": 2, "num_f_mask": 2, "max_t": 50, "max_f": 10, "prob": cfg.get("prob", 0.5)}
+                    self.spec_aug.update({k: params.get(k, v) for k, v in defaults.items()})
+            # The reference decodes (and resamples) a noise file per sample (reader.py:323);
+            # here every clip is decoded once and lives on the GPU.
+            for p in self.noise_files or []:
+                clip, sr = read_audio(p)
+                clip = clip.T
+                if clip.ndim > 1:
+                    clip = clip.mean(axis=0)
+                if sr != self.sample_rate:
+                    raise NotImplementedError(f"noise clip {p} is {sr} Hz: resampling is not on the GPU path yet")
+                self.noise_clips.append(np.ascontiguousarray(clip, dtype=np.float32))
+            self.planner = AugmentPlanner(self.augment_configs, [len(c) for c in self.noise_clips],
+                                          len(self.rir_files or []))
+            if self.noise_clips:
+                _NOISE_CLIPS[id(processor)] = self.noise_clips
+
+    @staticmethod
+    def _load_wav_files(data_dir):
+        """reader.py:100-107"""
+        found = []
+        if os.path.exists(data_dir):
+            for root, _, files in os.walk(data_dir):
+                found += [os.path.join(root, f) for f in files if f.endswith(".wav")]
+        return found
+
+    def _load_data_list(self):
+        """reader.py:110-131"""
+        self._binary = None
+        if self.data_list_path.endswith(".header"):
+            self._binary = _BinaryManifest(self.data_list_path, self.min_duration, self.max_duration)
+            self.data_list = self._binary.keys
+            return
+        self.data_list = []
+        with open(self.data_list_path, "r", encoding="utf-8") as f:
+            for line in f:
+                rec = json.loads(line)
+                if not isinstance(rec, dict):
+                    continue
+                if rec["duration"] < self.min_duration:
+                    continue
+                if self.max_duration != -1 and rec["duration"] > self.max_duration:
+                    continue
+                self.data_list.append(dict(rec))
+
+    def __len__(self):
+        return len(self.data_list)
+
+    def _get_list_data(self, idx):
+        """reader.py:134-162 up to, not including, the sample arithmetic: decode,
+        transpose, mono, then the augmentation DECISIONS (not their application)."""
+        rec = self._binary.get(self.data_list[idx]) if self._binary else self.data_list[idx]
+        path = rec["audio"]["path"]
+        transcript = rec["sentences"] if self.timestamps else rec["sentence"]
+        language = rec["language"] if "language" in rec else None
+        if idx in self._decoded:
+            sample, sr = self._decoded.pop(idx)
+        elif "start_time" not in rec["audio"]:
+            sample, sr = read_audio(path)
+        else:
+            sample, sr = read_audio(path, rec["audio"]["start_time"], rec["audio"]["end_time"])
+        sample = sample.T
+        if self.mono and sample.ndim > 1:
+            sample = np.mean(sample, axis=0)                  # librosa.to_mono
+        sample = np.ascontiguousarray(sample, dtype=np.float32)
+        ops = []
+        if self.augment_configs:
+            ops, _ = self.planner.draw(len(sample), sr)
+        if self.sample_rate != sr:
+            raise NotImplementedError(f"{path} is {sr} Hz: resampling to {self.sample_rate} Hz is not on the GPU "
+                                      "path yet (SURVEY 8f N2)")
+        return rec["id"] if "id" in rec else path, sample, sr, transcript, language, ops
+
+    def _load_timestamps_transcript(self, transcript: List[dict]):
+        """reader.py:164-179: <|t|> tokens are timestamp_begin + centiseconds // 2, odd
+        centiseconds nudged inwards (start + 0.01, end - 0.01)."""
+        assert isinstance(transcript, list), f"transcript should be a list, got {type(transcript)}"
+        labels = list(self.processor.tokenizer.prefix_tokens[:3])
+        for t in transcript:
+            start = t["start"] if round(t["start"] * 100) % 2 == 0 else t["start"] + 0.01
+            start = self.timestamp_begin + round(start * 100) // 2
+            end = t["end"] if round(t["end"] * 100) % 2 == 0 else t["end"] - 0.01
+            end = self.timestamp_begin + round(end * 100) // 2
+            ids = self.processor.tokenizer(t["text"]).input_ids[4:-1]
+            labels.extend([start])
+            labels.extend(ids)
+            labels.extend([end])
+        return labels + [self.endoftext]
+
+    def __getitem__(self, idx):
+        try:
+            audio_id, sample, sr, transcript, language, ops = self._get_list_data(idx)
+            self.processor.tokenizer.set_prefix_tokens(language=language if language is not None else self.language)
+            if len(transcript) > 0:
+                if self.timestamps:
+                    labels = self._load_timestamps_transcript(transcript)
+                else:
+                    labels = self.processor.tokenizer(transcript).input_ids
+            else:
+                labels = [self.startoftranscript, self.nocaptions, self.endoftext]
+            item = {"waveform": sample, "aug_ops": ops, "labels": labels, "id": audio_id, "specaug": False}
+            if self.augment_configs and self.spec_aug:
+                if random.random() < self.spec_aug.get("prob"):
+                    item["specaug"] = self._draw_spec_augmentation()
+            return item
+        except Exception as e:  # noqa: BLE001  -- the reference swallows every error per sample
+            print(f"error reading sample {idx}: {e}", file=sys.stderr)
+            return {"input_features": None, "labels": None, "id": f"error_{idx}"}
+
+    def __getitems__(self, indices):
+        """Batched fetch used by the DataLoader when num_workers=0: the files of one
+        batch are decoded by a small thread pool (libsndfile releases the GIL), then
+        the per-sample work that draws random numbers runs in index order so that the
+        ``random`` stream is consumed exactly as by sequential __getitem__ calls."""
+        if len(indices) > 1 and self._pool_size > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            if self._pool is None:
+                self._pool = ThreadPoolExecutor(self._pool_size)
+
+            def decode(idx):
+                try:
+                    rec = self._binary.get(self.data_list[idx]) if self._binary else self.data_list[idx]
+                    a = rec["audio"]
+                    return read_audio(a["path"], a.get("start_time"), a.get("end_time")) if "start_time" in a \
+                        else read_audio(a["path"])
+                except Exception as e:  # noqa: BLE001 -- surfaced again (and reported) by __getitem__
+                    return e
+            for idx, res in zip(indices, self._pool.map(decode, indices)):
+                if not isinstance(res, Exception):
+                    self._decoded[idx] = res
+        try:
+            return [self[i] for i in indices]
+        finally:
+            self._decoded.clear()
+
+    def _draw_spec_augmentation(self):
+        """reader.py:355-389 applied to the real layout (1, n_mel, 3000): ``max_frames
+        = y.size(0) = 1`` so every time mask is ``y[0:1, :] = 0`` -- the whole tensor
+        (recorded, not "fixed").  The draws are consumed exactly as the
+        reference consumes them; the collator zero-fills the item."""
+        n_mel = self.processor.feature_extractor.feature_size
+        zero_all, rows = False, []
+        for _ in range(self.spec_aug["num_t_mask"]):
+            random.randint(0, 0)                                  # start in [0, max_frames - 1] = [0, 0]
+            random.randint(1, self.spec_aug["max_t"])
+            zero_all = True                                       # y[0:1, :] = 0
+        for _ in range(self.spec_aug["num_f_mask"]):
+            start = random.randint(0, n_mel - 1)                  # max_freq = y.size(1) = n_mel
+            length = random.randint(1, self.spec_aug["max_f"])
+            rows.append((start, min(n_mel, start + length)))      # y[:, start:end] = 0 -> mel rows
+        return {"all": zero_all, "rows": rows}
+
+
+# ------------------------------------------------------------------ collators
+def _pad_labels(rows: List[List[int]], strip_token: Optional[int]) -> torch.Tensor:
+    width = max((len(r) for r in rows), default=0)
+    out = torch.full((len(rows), width), -100, dtype=torch.int64)
+    for i, r in enumerate(rows):
+        out[i, :len(r)] = torch.as_tensor(r, dtype=torch.int64)
+    # training convention of the upstream project (not verifiable in the reference
+    # tree): drop a leading BOS shared by every row; the model re-adds the decoder
+    # start token by shifting the labels right
+    if strip_token is not None and width > 0 and len(rows) > 0 and bool((out[:, 0] == strip_token).all()):
+        out = out[:, 1:]
+    return out
+
+
+class DataCollatorSpeechSeq2SeqWithPadding:
+    """``DataCollatorSpeechSeq2SeqWithPadding(processor=processor)`` (finetune.py:70).
+    ``device_output=True`` keeps ``input_features`` on the GPU (needs
+    ``dataloader_pin_memory=False``); the default returns CPU tensors like the
+    reference's DataLoader batches."""
+
+    keep_prompt = False
+    with_ids = False
+
+    def __init__(self, processor: Any, device=None, device_output: Optional[bool] = None, noise_clips=None):
+        self.processor = processor
+        self.device = device
+        self.device_output = (os.environ.get("WFE_DEVICE_OUTPUT", "0") == "1") if device_output is None \
+            else bool(device_output)
+        self._noise_src = noise_clips
+        self._noise_bank = None
+
+    def set_noise_clips(self, clips):
+        """The decoded noise clips of ``CustomDataset.noise_clips`` (uploaded once)."""
+        self._noise_src, self._noise_bank = clips, None
+
+    def _features(self, items):
+        fe_cfg = self.processor.feature_extractor
+        n_mel, n_samples = fe_cfg.feature_size, fe_cfg.n_samples
+        frames = n_samples // fe_cfg.hop_length
+        gpu_items = [i for i, it in enumerate(items) if "waveform" in it]
+        feats = [None] * len(items)
+        if gpu_items:
+            if torch.utils.data.get_worker_info() is not None:
+                raise RuntimeError("the GPU collator must run in the rank's main process: a forked DataLoader "
+                                   "worker cannot use the GPU -- launch with --num_workers 0 (host decode is "
+                                   "parallelised inside CustomDataset.__getitems__)")
+            from .feature_extractor import front_end
+            from .frontend import NoiseBank, pack_ragged
+            fe = front_end(n_mel, self.device)
+            flat, off, lens = pack_ragged([items[i]["waveform"] for i in gpu_items], fe.device)
+            plans = [items[i].get("aug_ops") or [] for i in gpu_items]
+            if any(plans):
+                src = self._noise_src if self._noise_src is not None else _NOISE_CLIPS.get(id(self.processor))
+                if self._noise_bank is None and src:
+                    self._noise_bank = NoiseBank(src, fe.device)
+                out = fe.augment_logmel(flat, lens, plans, self._noise_bank, n_samples=n_samples, offsets=off)
+            else:
+                out = fe.logmel(flat, lens, n_samples=n_samples, offsets=off)
+            for j, i in enumerate(gpu_items):             # reader.py:355-389 on the (1, M, T) layout
+                sa = items[i].get("specaug")
+                if sa:
+                    if sa["all"]:
+                        out[j] = 0.0
+                    for (r0, r1) in sa["rows"]:
+                        out[j, r0:r1] = 0.0
+            if len(gpu_items) == len(items):
+                return out if self.device_output else out.cpu()
+            out = out.cpu()
+            for j, i in enumerate(gpu_items):
+                feats[i] = out[j]
+        for i, it in enumerate(items):                 # features that arrive already computed
+            if feats[i] is None:
+                f = it["input_features"]
+                f = f if isinstance(f, torch.Tensor) else torch.from_numpy(np.asarray(f))
+                feats[i] = f.reshape(n_mel, -1).to(torch.float32)
+                assert feats[i].shape[1] == frames
+        return torch.stack(feats, dim=0)
+
+    def __call__(self, features: List[dict]) -> dict:
+        items = [f for f in features if ("waveform" in f) or (f.get("input_features") is not None)]
+        fe_cfg = self.processor.feature_extractor
+        if not items:
+            batch = {"input_features": torch.zeros((0, fe_cfg.feature_size, fe_cfg.n_samples // fe_cfg.hop_length)),
+                     "labels": torch.zeros((0, 0), dtype=torch.int64)}
+            if self.with_ids:
+                batch["id"] = []
+            return batch
+        strip = None if self.keep_prompt else getattr(self.processor.tokenizer, "bos_token_id", None)
+        batch = {"input_features": self._features(items),
+                 "labels": _pad_labels([list(f["labels"]) for f in items], strip)}
+        if self.with_ids:
+            batch["id"] = [f["id"] for f in items]
+        return batch
+
+
+class DataCollatorSpeechSeq2SeqWithPaddingforEval(DataCollatorSpeechSeq2SeqWithPadding):
+    """evaluation.py:63: also returns ``id``; ``labels[:, :4]`` stay the prompt tokens."""
+
+    keep_prompt = True
+    with_ids = True
+
+
+# ------------------------------------------------------------------ text helpers
+_PUNCT = '!,.;:?、！，。；：？《》「」『』【】（）()"' + "'“”‘’"
+
+
+def remove_punctuation(text):
+    """evaluation.py:116-118: strips punctuation from a str or a list of str."""
+    if isinstance(text, str):
+        return "".join(ch for ch in text if ch not in _PUNCT).strip()
+    if isinstance(text, list):
+        return [remove_punctuation(t) for t in text]
+    raise TypeError(f"unsupported type {type(text)}")
+
+
+def to_simple(text):
+    """evaluation.py:120-122: traditional -> simplified Chinese (zhconv, as upstream)."""
+    try:
+        from zhconv import convert
+    except ImportError as e:       # noqa: F841
+        raise ImportError("to_simple needs the 'zhconv' package the reference lists in requirements.txt")
+    if isinstance(text, str):
+        return convert(text, "zh-cn")
+    if isinstance(text, list):
+        return [convert(t, "zh-cn") for t in text]
+    raise TypeError(f"unsupported type {type(text)}")
+
+
+def to_lower(text):
+    """evaluation.py:123-125"""
+    if isinstance(text, str):
+        return text.lower()
+    if isinstance(text, list):
+        return [t.lower() for t in text]
+    raise TypeError(f"unsupported type {type(text)}")
