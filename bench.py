@@ -191,6 +191,15 @@ def main() -> None:
         clips = args.batch * args.steps * world
         k1_avg_s = k1_ms / max(launches, 1) / 1e3
         achieved = ALGO_GFLOP[args.n_mel] * args.batch / k1_avg_s / 1e3          # TFLOP/s
+        traffic, traffic_src = None, None
+        try:   # HBM bytes per launch measured offline with rocprofv3 PMC passes (same batch / n_mel only)
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            if tj["batch"] == args.batch and tj["n_mel"] == args.n_mel:
+                traffic = (tj["frontend_kernel"]["fetch_bytes"] + tj["frontend_kernel"]["write_bytes"]) / 1e9
+                traffic_src = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, GB per launch; " \
+                              "algorithmic %.3f GB)" % (ALGO_BYTES[args.n_mel] * args.batch / 1e9)
+        except Exception:  # noqa: BLE001
+            pass
         line = {
             "metric": "log-mel audio-hours/sec",
             "value": clips * CLIP_HOURS / elapsed,
@@ -211,10 +220,14 @@ def main() -> None:
             "clips_per_sec": clips / elapsed,
             "roofline": {
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "wfe::frontend_kernel", "kernel_ms_avg": k1_avg_s * 1e3, "launches": launches,
                 "algorithmic_gflop_per_clip": ALGO_GFLOP[args.n_mel],
-                "executed_mfma_gflop_per_clip": 2 * 3008 * 4 * 100 * 112 / 1e9,
+                # what the folded-DFT kernel actually issues: 47 blocks x 4 waves x (700 DFT + 72|84 mel)
+                # v_mfma_f32_16x16x4_f32 of 2048 FLOP each
+                "executed_mfma_gflop_per_clip": 47 * 4 * (700 + (72 if args.n_mel <= 80 else 84)) * 2048 / 1e9,
+                "executed_mfma_tflops": 47 * 4 * (700 + (72 if args.n_mel <= 80 else 84)) * 2048 * args.batch
+                / k1_avg_s / 1e12,
                 "clamp_kernel_ms_avg": k2_ms / max(launches, 1),
                 "hbm_algorithmic_gbs": ALGO_BYTES[args.n_mel] * args.batch / k1_avg_s / 1e9,
             },

@@ -233,6 +233,9 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   const f32x4* __restrict__ gtab = reinterpret_cast<const f32x4*>(a.dft_tab) + tid;
   f32x4* const slots = reinterpret_cast<f32x4*>(lds + kLdsWaveFloats);       // 2 x 512 float4
   f32x4 g0 = gtab[0], g1 = gtab[256], g2 = gtab[512], g3 = gtab[768];
+  f32x4 ga[2], gb[2];                      // staging registers, ping-pong: A(s+2) / A(s+3)
+  ga[0] = gtab[1024];
+  ga[1] = gtab[1280];
 
   // ---- stage the padded-signal span [160 t0, 160 t0 + 10480) into LDS
   {
@@ -319,11 +322,12 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   // workgroup instead of once per wave.  Everything a step consumes was requested
   // a whole step earlier, and the requests are dealt out between the MFMAs of the
   // step in four small batches so that the matrix pipe never waits on their issue:
-  //   step s:  MFMA 1       | global->reg A(s+2) (32 B/thread), LDS->reg fragments g=0 of A(s+1)
-  //            MFMA 2..7    | LDS->reg fragments g=1, samples of step s+1
+  //   step s:  MFMA 1       | global->reg A(s+3) (32 B/thread), LDS->reg fragments g=0 of A(s+1)
+  //            MFMA 2..7    | reg->LDS A(s+2) into slot s&1 (fetched during step s-1; the slot was
+  //                         |   read out in step s-1), LDS->reg fragments g=1, samples of step s+1
   //            MFMA 8..14   | fragments g=2
   //            MFMA 15..21  | fragments g=3
-  //            MFMA 22..28  | reg->LDS A(s+2) into slot s&1 (read out in step s-1) | barrier
+  //            MFMA 22..28  | barrier
   // What keeps hipcc from serialising this (checked in the .s): the two fragment
   // register sets ping-pong (a single set plus a copy gets the copy, and its wait,
   // hoisted to a few MFMAs after the reads); scheduling barriers pin each batch
@@ -351,6 +355,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) Ra[g] = load_frag7(slots + lane + g * 128);
   sample_request(0);
+  __syncthreads();      // slot 0 is overwritten in the middle of step 0: every wave must have read it out
 #pragma unroll
   for (int s = 0; s < kSteps; ++s) {
     Frag7(&Rc)[4] = (s & 1) ? Rb : Ra;
@@ -367,17 +372,23 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
       acc[g][bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rc[g].at(bt), (g & 1) ? o[g >> 1] : e[g >> 1], acc[g][bt],
                                                         0, 0, 0);
     };
+    f32x4(&Gw)[2] = (s & 1) ? gb : ga;      // holds A(s+2), requested during step s-1
+    f32x4(&Gr)[2] = (s & 1) ? ga : gb;      // receives A(s+3)
     mfma(0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (stage) {
-      g0 = gtab[(s + 2) * 512];
-      g1 = gtab[(s + 2) * 512 + 256];
+    if (s + 3 < kSteps) {
+      Gr[0] = gtab[(s + 3) * 512];
+      Gr[1] = gtab[(s + 3) * 512 + 256];
     }
     if (next) Rn[0] = load_frag7(nslot);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int bt = 1; bt < 7; ++bt) mfma(0, bt);
     __builtin_amdgcn_sched_barrier(0);
+    if (stage) {
+      slots[(s & 1) * 512 + tid] = Gw[0];
+      slots[(s & 1) * 512 + 256 + tid] = Gw[1];
+    }
     if (next) {
       Rn[1] = load_frag7(nslot + 128);
       sample_request(s + 1);
@@ -396,10 +407,6 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
 #pragma unroll
     for (int bt = 0; bt < 7; ++bt) mfma(3, bt);
     __builtin_amdgcn_sched_barrier(0);
-    if (stage) {
-      slots[(s & 1) * 512 + tid] = g0;
-      slots[(s & 1) * 512 + 256 + tid] = g1;
-    }
     if (next) __syncthreads();
   }
 

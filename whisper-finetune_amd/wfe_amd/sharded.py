@@ -58,7 +58,7 @@ def run_sharded(n_items: int, batch: int, make_batch: Callable[[int, int], tuple
     for b0 in range(begin, end, batch):
         count = min(batch, end - b0)
         out = transform(*make_batch(b0, count))
-        acc = acc.to(out.device) + out.double().sum()       # stays on the device; no host sync per batch
+        acc = acc.to(out.device) + out.sum(dtype=torch.float64)   # stays on the device; no host sync per batch
         done += count
     fence()
     elapsed = time.perf_counter() - t0
