@@ -194,6 +194,43 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   int raw_len = a.lengths[b];
   if (raw_len < 0) raw_len = 0;
   WFE_STAMP(0);
+  Chain c;
+  int len = raw_len;
+  if (AUG) {
+    c = make_chain(a, b, w, raw_len);
+    len = chain_len(c, c.n_ops);
+  }
+  if (len > n) len = n;                         // truncation=True (HF:300-307)
+  const int p0 = t0 * kHop;
+  const int i_first = p0 - kHalf;
+
+  // Silent workgroup: every padded-signal position of these 64 frames maps (after
+  // reflection at the end of the padded utterance) to the zero padding behind the
+  // utterance.  Every sample is 0, so every power and mel value is exactly 0 and the
+  // log-mel is exactly the floor log10(1e-10) = -10: written directly, no DFT.  For
+  // a 6 s utterance padded to 30 s that is 4/5 of the workgroups.
+  {
+    const int i_last = i_first + kBlockSamples - 1;
+    const bool silent = i_first >= len && (i_last < n || 2 * (n - 1) - i_last >= len);
+    if (silent) {
+      const int frames_here = (T - t0 < kBlockFrames) ? (T - t0) : kBlockFrames;
+      if (POWER) {
+        float* __restrict__ po = a.out + (long long)b * kNfreq * T + t0;
+        for (int idx = tid; idx < kNfreq * kBlockFrames; idx += 256) {
+          const int k = idx >> 6, fb = idx & 63;
+          if (fb < frames_here) po[(long long)k * T + fb] = 0.f;
+        }
+      } else {
+        float* __restrict__ lo = a.out + (long long)b * a.n_mel * T + t0;
+        for (int idx = tid; idx < a.n_mel * kBlockFrames; idx += 256) {
+          const int mel = idx >> 6, fb = idx & 63;
+          if (fb < frames_here) lo[(long long)mel * T + fb] = -10.0f;
+        }
+        if (tid == 0) atomicMax(a.clip_max + b, enc_max(-10.0f));
+      }
+      return;
+    }
+  }
 
   // Stagger (speed only, never correctness).  The two workgroups a CU holds are
   // dispatched together and, doing identical work, would stage, multiply and
@@ -239,15 +276,6 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
 
   // ---- stage the padded-signal span [160 t0, 160 t0 + 10480) into LDS
   {
-    Chain c;
-    int len = raw_len;
-    if (AUG) {
-      c = make_chain(a, b, w, raw_len);
-      len = chain_len(c, c.n_ops);
-    }
-    if (len > n) len = n;                       // truncation=True (HF:300-307)
-    const int p0 = t0 * kHop;
-    const int i_first = p0 - kHalf;
     const bool interior = !AUG && i_first >= 0 && i_first + kBlockSamples <= len &&
                           ((reinterpret_cast<uintptr_t>(w + i_first) & 15u) == 0);
     if (interior) {
