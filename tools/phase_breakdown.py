@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "whisper-finetune_amd"))
 from wfe_amd import _lib  # noqa: E402
 
-_lib.LIB_PATH = os.path.join(ROOT, "whisper-finetune_amd", "wfe_amd", "libwfe_hip_stamps.so")
+_lib.LIB_PATH = os.path.join(ROOT, "whisper-finetune_amd", "wfe_amd", os.environ.get("WFE_STAMP_LIB", "libwfe_hip_stamps.so"))
 from wfe_amd.frontend import HipFrontEnd  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
@@ -40,6 +40,7 @@ print("waves", len(s), "kernel span (cycles)", s[:, 5].max() - s[:, 0].min())
 for i, nme in enumerate(names):
     print(f"{nme:22s} median {np.median(d[:, i]):9.0f}  p10 {np.percentile(d[:, i], 10):9.0f}  p90 {np.percentile(d[:, i], 90):9.0f}")
 tot = s[:, 5] - s[:, 0]
+print(f"{'  k-loop barrier waits':22s} median {np.median(s[:, 7]):9.0f}  (sum over 24 barriers incl. 2 stamps each)")
 print(f"{'total':22s} median {np.median(tot):9.0f}  p10 {np.percentile(tot, 10):9.0f}  p90 {np.percentile(tot, 90):9.0f}")
 
 # co-residency: group waves by (xcc, se/sh/cu, simd) and measure how much of each wave's
@@ -48,7 +49,7 @@ hw = s[:, 6] & 0xffffffff
 xcc = s[:, 6] >> 32
 key = (xcc << 16) | (((hw >> 8) & 255) << 4) | ((hw >> 4) & 3)
 print("distinct (xcc,cu,simd):", len(np.unique(key)), " distinct (xcc,cu):", len(np.unique(key >> 4)),
-      " tickets==1:", int((s[:, 7] == 1).sum()) // 4, " ticket max:", int(s[:, 7].max()))
+     )
 ov, tot_k = 0, 0
 for k in np.unique(key)[:200]:
     w = s[key == k]

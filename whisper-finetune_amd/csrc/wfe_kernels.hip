@@ -350,12 +350,13 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   // workgroup instead of once per wave.  Everything a step consumes was requested
   // a whole step earlier, and the requests are dealt out between the MFMAs of the
   // step in four small batches so that the matrix pipe never waits on their issue:
-  //   step s:  MFMA 1       | global->reg A(s+3) (32 B/thread), LDS->reg fragments g=0 of A(s+1)
-  //            MFMA 2..7    | reg->LDS A(s+2) into slot s&1 (fetched during step s-1; the slot was
-  //                         |   read out in step s-1), LDS->reg fragments g=1, samples of step s+1
-  //            MFMA 8..14   | fragments g=2
-  //            MFMA 15..21  | fragments g=3
-  //            MFMA 22..28  | barrier
+  //   step s:  MFMA 1,2    | global->reg A(s+3) (2 x 16 B/thread)
+  //            MFMA 3,4    | reg->LDS A(s+2) into slot s&1 (fetched during step s-1; the slot was
+  //                        |   read out in step s-1)
+  //            MFMA 5..12  | LDS->reg the 8 fragment pieces of A(s+1)
+  //            MFMA 13..16 | LDS->reg the 4 samples of step s+1
+  //            MFMA 17..28 | barrier
+  //   (one request behind each MFMA, pinned there)
   // What keeps hipcc from serialising this (checked in the .s): the two fragment
   // register sets ping-pong (a single set plus a copy gets the copy, and its wait,
   // hoisted to a few MFMAs after the reads); scheduling barriers pin each batch
@@ -363,26 +364,28 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   // read (a dead destination register is reused at once and forces a wait).
   float xf[2], xb[2];
   const int lane_lo = rowbase + d_lo, lane_hi = rowbase + d_hi;
-  auto sample_request = [&](int s) {
+  auto sample_request = [&](int s, int c, int backward) {
     // n = dft_n_of(c, s, kk) = nb + delta(lane) + c0, c0 = 2 (even class) or 1 (odd)
     const bool tail = s == kSteps - 1;
     const int nb = tail ? 192 : (32 * (s >> 2) + 4 * (s & 3));
     const int dl = tail ? d_hi : d_lo;
     const int base = tail ? lane_hi : lane_lo;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int nn = nb + dl + (c ? 1 : 2);            // 1..200
-      const int mm = kNfft - nn;                       // 200..399
-      // pad_q(160 j + x) = 161 j + x + x / 160; the x / 160 term is a compile-time
-      // constant except in the few steps whose 4 k-lanes straddle 160 or 320
-      xf[c] = lds[base + nb + (c ? 1 : 2) + (nn >= kHop ? 1 : 0)];
-      xb[c] = lds[2 * rowbase - base + kNfft - nb - (c ? 1 : 2) + 1 + (mm >= 2 * kHop ? 1 : 0)];
-    }
+    const int c0 = c ? 1 : 2;
+    const int nn = nb + dl + c0;                       // 1..200
+    const int mm = kNfft - nn;                         // 200..399
+    // pad_q(160 j + x) = 161 j + x + x / 160; the x / 160 term is a compile-time
+    // constant except in the few steps whose 4 k-lanes straddle 160 or 320
+    if (backward) xb[c] = lds[2 * rowbase - base + kNfft - nb - c0 + 1 + (mm >= 2 * kHop ? 1 : 0)];
+    else xf[c] = lds[base + nb + c0 + (nn >= kHop ? 1 : 0)];
   };
+#ifdef WFE_STAMPS
+  unsigned long long barrier_cycles = 0;
+#endif
   Frag7 Ra[4], Rb[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) Ra[g] = load_frag7(slots + lane + g * 128);
-  sample_request(0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sample_request(0, i >> 1, i & 1);
   __syncthreads();      // slot 0 is overwritten in the middle of step 0: every wave must have read it out
 #pragma unroll
   for (int s = 0; s < kSteps; ++s) {
@@ -397,48 +400,66 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
       o[c] = xf[c] - xb[c];
     }
     auto mfma = [&](int g, int bt) {
+#ifdef WFE_AGPR_ACC
+      asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0"
+                   : "+a"(acc[g][bt])
+                   : "v"(Rc[g].at(bt)), "v"((g & 1) ? o[g >> 1] : e[g >> 1]));
+#else
       acc[g][bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rc[g].at(bt), (g & 1) ? o[g >> 1] : e[g >> 1], acc[g][bt],
                                                         0, 0, 0);
+#endif
     };
     f32x4(&Gw)[2] = (s & 1) ? gb : ga;      // holds A(s+2), requested during step s-1
     f32x4(&Gr)[2] = (s & 1) ? ga : gb;      // receives A(s+3)
-    mfma(0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (s + 3 < kSteps) {
-      Gr[0] = gtab[(s + 3) * 512];
-      Gr[1] = gtab[(s + 3) * 512 + 256];
-    }
-    if (next) Rn[0] = load_frag7(nslot);
-    __builtin_amdgcn_sched_barrier(0);
+    // the 16 requests of a step, one behind each of the first 16 MFMAs (a clump of
+    // them between two MFMAs idles the matrix pipe for the clump's issue time)
+#ifndef WFE_EXP
+#define WFE_EXP 0
+#endif
+    auto request = [&](int i) {
+      if (i < 2) {                                          // global -> registers, A(s+3)
+        // uniform base + 32-bit thread offset: a scalar-base load, no 64-bit VALU address math
+        if (s + 3 < kSteps && !(WFE_EXP & 1))
+          Gr[i] = reinterpret_cast<const f32x4*>(a.dft_tab)[(s + 3) * 512 + 256 * i + (unsigned)tid];
+      } else if (i < 4) {                                   // registers -> LDS, A(s+2)
+        if (stage && !(WFE_EXP & 2)) slots[(s & 1) * 512 + 256 * (i - 2) + tid] = Gw[i - 2];
+      } else if (i < 12) {                                  // LDS -> registers, fragments of A(s+1)
+        const int g = (i - 4) >> 1;
+        if (next && !(WFE_EXP & 4)) {
+          if ((i - 4) & 1) Rn[g].hi = *reinterpret_cast<const f32x3*>(nslot + g * 128 + 64);
+          else Rn[g].lo = nslot[g * 128];
+        }
+      } else if (next && !(WFE_EXP & 8)) {                  // LDS -> registers, samples of step s+1
+        sample_request(s + 1, (i - 12) >> 1, (i - 12) & 1);
+      }
+    };
 #pragma unroll
-    for (int bt = 1; bt < 7; ++bt) mfma(0, bt);
-    __builtin_amdgcn_sched_barrier(0);
-    if (stage) {
-      slots[(s & 1) * 512 + tid] = Gw[0];
-      slots[(s & 1) * 512 + 256 + tid] = Gw[1];
+    for (int m = 0; m < 28; ++m) {
+      mfma(m / 7, m % 7);
+      __builtin_amdgcn_sched_barrier(0);
+      if (m < 16) {
+        request(m);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
+#ifdef WFE_STAMPS
     if (next) {
-      Rn[1] = load_frag7(nslot + 128);
-      sample_request(s + 1);
+      unsigned long long tb0, tb1;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb0)::"memory");
+      __syncthreads();
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb1)::"memory");
+      barrier_cycles += tb1 - tb0;
     }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int bt = 0; bt < 7; ++bt) mfma(1, bt);
-    __builtin_amdgcn_sched_barrier(0);
-    if (next) Rn[2] = load_frag7(nslot + 256);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int bt = 0; bt < 7; ++bt) mfma(2, bt);
-    __builtin_amdgcn_sched_barrier(0);
-    if (next) Rn[3] = load_frag7(nslot + 384);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int bt = 0; bt < 7; ++bt) mfma(3, bt);
-    __builtin_amdgcn_sched_barrier(0);
+#else
     if (next) __syncthreads();
+#endif
   }
 
   WFE_STAMP(3);
+#ifdef WFE_STAMPS
+  if (a.stamps && lane == 0)
+    a.stamps[((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8 + 7] = barrier_cycles;
+#endif
   // Mel weight fragments of every live (bin tile, mel tile) block: all requested
   // here, ahead of the butterflies, so that the mel phase pays one L2 round trip
   // instead of one per block (the scheduling barrier pins the batch).
