@@ -33,6 +33,8 @@ struct wfe_context {
   bool timing = false;
   std::vector<hipEvent_t> ev_pool;      // triples: before K1, after K1, after K2
   size_t ev_used = 0;
+  float* d_block_min = nullptr;             // per-wave minima of kernel 1, grows on demand
+  size_t block_min_cap = 0;
   unsigned long long* d_stamps = nullptr;   // diagnostic builds only (wfe_debug_stamps)
   std::string err;
 };
@@ -99,6 +101,7 @@ void fill_args(wfe_context* h, wfe::FrontArgs& a, const float* wav, const int64_
   std::memcpy(a.mel_mask, h->mel_mask, sizeof a.mel_mask);
   a.clip_max = h->d_clip_max;
   a.cu_tickets = h->d_clip_max + kMaxBatchPerLaunch;
+  a.block_min = h->d_block_min;
   a.stamps = h->d_stamps;
 }
 
@@ -159,6 +162,17 @@ int run_frontend(wfe_context* h, const float* wav, const int64_t* offsets, const
     if (rc != WFE_OK) return rc;
   }
   const int T = n_samples / wfe::kHop;
+  if (mode == 0) {
+    const size_t per_slice = (size_t)(batch < kMaxBatchPerLaunch ? batch : kMaxBatchPerLaunch) *
+                             ((T + wfe::kBlockFrames - 1) / wfe::kBlockFrames) * 4;
+    if (per_slice > h->block_min_cap) {
+      if (h->d_block_min) HIP_TRY(h, hipFree(h->d_block_min));
+      h->d_block_min = nullptr;
+      h->block_min_cap = 0;
+      HIP_TRY(h, hipMalloc(&h->d_block_min, per_slice * 2 * sizeof(float)));
+      h->block_min_cap = per_slice * 2;
+    }
+  }
   const long long per_clip = (mode == 1) ? (long long)wfe::kNfreq * T : (long long)h->cfg.n_mel * T;
   for (const Slice& s : slices(batch)) {
     wfe::FrontArgs a;
@@ -194,7 +208,8 @@ int run_frontend(wfe_context* h, const float* wav, const int64_t* offsets, const
     }
     HIP_TRY(h, wfe::launch_frontend(a, s.count, mode, aug, h->bank, stream));
     if (ev) HIP_TRY(h, hipEventRecord(ev[1], stream));
-    if (mode == 0) HIP_TRY(h, wfe::launch_clamp(a.out, h->d_clip_max, s.count, per_clip, stream));
+    if (mode == 0)
+      HIP_TRY(h, wfe::launch_clamp(a.out, h->d_clip_max, h->d_block_min, s.count, h->cfg.n_mel, T, stream));
     if (ev) HIP_TRY(h, hipEventRecord(ev[2], stream));
   }
   return WFE_OK;
@@ -263,6 +278,7 @@ int wfe_destroy(wfe_handle h) {
   if (h->d_clip_max) (void)hipFree(h->d_clip_max);
   if (h->d_resolved) (void)hipFree(h->d_resolved);
   if (h->d_noise_meansq) (void)hipFree(h->d_noise_meansq);
+  if (h->d_block_min) (void)hipFree(h->d_block_min);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   delete h;
   return WFE_OK;

@@ -31,6 +31,7 @@ struct FrontArgs {
   // output
   float* out;                    // (B, n_mel, T) log10 mel power, or (B, 201, T) power
   unsigned* clip_max;            // (B) order-preserving encoding of max log10
+  float* block_min;              // (B x workgroups per utterance x 4 waves) minimum log10 mel of each wave
   unsigned* cu_tickets;          // (4096) arrival counters per CU, zeroed with clip_max (stagger heuristic)
   // augmentation (AUG kernels only)
   const wfe_aug_op* ops;
@@ -44,8 +45,9 @@ struct FrontArgs {
 
 // mode 0: log10 mel + clip max.  mode 1: power spectrum.
 hipError_t launch_frontend(const FrontArgs& a, int batch, int mode, bool augmented, int bank, hipStream_t stream);
-// (x > max-8 ? x : max-8) + 4) / 4 in place over (batch, per_clip)
-hipError_t launch_clamp(float* out, const unsigned* clip_max, int batch, long long per_clip, hipStream_t stream);
+// max(stored, g(max-8)) over the tiles whose minimum is below max-8 (kernel 1 stored g(v) = (v+4)/4)
+hipError_t launch_clamp(float* out, const unsigned* clip_max, const float* block_min, int batch, int n_mel,
+                        int n_frames, hipStream_t stream);
 // mean squares of the noise clips (once per noise bank)
 hipError_t launch_noise_meansq(const float* noise, const long long* noise_off, int n_noise, double* meansq,
                                hipStream_t stream);

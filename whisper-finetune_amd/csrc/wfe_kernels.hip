@@ -11,16 +11,19 @@
 // wfe_layout.h) x 7 bin tiles = 28 accumulators of v_mfma_f32_16x16x4_f32,
 // K = 100 in 25 k-steps.  B operands (e = x[n]+x[400-n], o = x[n]-x[400-n]) are
 // built from two ds_read_b32 of the LDS tile; A operands (Hann-windowed twiddles,
-// fp64-built, L2 resident, 200 KB) are fetched one k-step ahead straight into
-// registers as 8 x float4 per lane (perfectly coalesced 1 KB wave loads, L1/L2
-// hits), so the k-loop has no barrier.  The butterflies
+// fp64-built, L2 resident, 200 KB): the 8 KB of one k-step are shared by the 4
+// waves through a double-buffered LDS slot (global -> registers two steps ahead,
+// registers -> LDS one step ahead, ds_read_b128 + b96 into ping-pong fragment
+// registers one step ahead), one barrier per k-step.  The butterflies
 // Ce+-Co / Se+-So and |.|^2 run on the accumulators, whose C/D layout (frame on
 // the lane, bins in registers) is exactly the B layout the mel MFMA wants, so the
 // power spectrum never leaves registers.  Epilogue: log10, per-wave max ->
 // one atomicMax per wave on the utterance's max word; the block's (n_mel x 64)
 // output tile is transposed through LDS and leaves as 256-byte row segments.
 //
-// Kernel 2 (clamp_kernel): max(x, clipmax - 8), (x + 4) / 4, float4 in place.
+// Kernel 2 (clamp_kernel): kernel 1 stores (x + 4) / 4 and each workgroup's minimum;
+// kernel 2 applies max(., g(clipmax - 8)) only to the tiles whose minimum is below
+// clipmax - 8 (bit-identical to clamping first: the map is monotone).
 //
 // Numerics: f32 MFMA is a k-ordered fmaf chain (exact f32).  Tables are built in
 // float64 and rounded once.
@@ -207,26 +210,25 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   // Silent workgroup: every padded-signal position of these 64 frames maps (after
   // reflection at the end of the padded utterance) to the zero padding behind the
   // utterance.  Every sample is 0, so every power and mel value is exactly 0 and the
-  // log-mel is exactly the floor log10(1e-10) = -10: written directly, no DFT.  For
+  // log-mel is exactly the floor log10(1e-10) = -10: no DFT, and no store either (below).  For
   // a 6 s utterance padded to 30 s that is 4/5 of the workgroups.
   {
     const int i_last = i_first + kBlockSamples - 1;
     const bool silent = i_first >= len && (i_last < n || 2 * (n - 1) - i_last >= len);
     if (silent) {
-      const int frames_here = (T - t0 < kBlockFrames) ? (T - t0) : kBlockFrames;
       if (POWER) {
+        const int frames_here = (T - t0 < kBlockFrames) ? (T - t0) : kBlockFrames;
         float* __restrict__ po = a.out + (long long)b * kNfreq * T + t0;
         for (int idx = tid; idx < kNfreq * kBlockFrames; idx += 256) {
           const int k = idx >> 6, fb = idx & 63;
           if (fb < frames_here) po[(long long)k * T + fb] = 0.f;
         }
       } else {
-        float* __restrict__ lo = a.out + (long long)b * a.n_mel * T + t0;
-        for (int idx = tid; idx < a.n_mel * kBlockFrames; idx += 256) {
-          const int mel = idx >> 6, fb = idx & 63;
-          if (fb < frames_here) lo[(long long)mel * T + fb] = -10.0f;
-        }
+        // Nothing is written here: the tile is the constant g(-10) = -1.5 before the
+        // clamp, so kernel 2 (which knows the utterance maximum) writes its final value
+        // once.  -inf marks the tile as silent; real minima are >= -10.
         if (tid == 0) atomicMax(a.clip_max + b, enc_max(-10.0f));
+        if (tid < 4) a.block_min[((long long)b * gridDim.x + blockIdx.x) * 4 + tid] = -INFINITY;
       }
       return;
     }
@@ -545,7 +547,10 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   // -10 and the floor is by far the most common value (silence, padding), so it is
   // produced exactly; above it v_log_f32 * log10(2) is within 1.2e-6 of log10.
   float* const tile = lds + kLdsWaveFloats;            // [16 * NMT][kTileStride]
-  float wmax = -INFINITY;
+  // The value stored is already (v + 4) / 4: that map is monotone, so the max-8 clamp
+  // of kernel 2 commutes with it exactly, max(g(v), g(max-8)) == g(max(v, max-8)), and
+  // kernel 2 only has to touch the workgroups whose minimum lies below max-8.
+  float wmax = -INFINITY, wmin = INFINITY;
   const bool frame_ok = frame < T;
 #pragma unroll
   for (int mt = 0; mt < NMT; ++mt)
@@ -554,12 +559,21 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
       const int mel = 16 * mt + 4 * kk + r;
       const float pw = m[mt][r];
       const float v = (pw > 1e-10f) ? __builtin_amdgcn_logf(pw) * 0.30102999566398120f : -10.0f;
-      tile[mel * kTileStride + wave * 16 + jl] = v;
-      if (frame_ok && mel < a.n_mel) wmax = fmaxf(wmax, v);
+      tile[mel * kTileStride + wave * 16 + jl] = (v + 4.0f) * 0.25f;
+      if (frame_ok && mel < a.n_mel) {
+        wmax = fmaxf(wmax, v);
+        wmin = fminf(wmin, v);
+      }
     }
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, d, 64));
-  if (lane == 0 && wmax > -INFINITY) atomicMax(a.clip_max + b, enc_max(wmax));
+  for (int d = 32; d >= 1; d >>= 1) {
+    wmax = fmaxf(wmax, __shfl_xor(wmax, d, 64));
+    wmin = fminf(wmin, __shfl_xor(wmin, d, 64));
+  }
+  if (lane == 0) {
+    if (wmax > -INFINITY) atomicMax(a.clip_max + b, enc_max(wmax));
+    a.block_min[((long long)b * gridDim.x + blockIdx.x) * 4 + wave] = wmin;
+  }
   __syncthreads();
   float* __restrict__ lo = a.out + (long long)b * a.n_mel * T + t0;
   const int frames_here = (T - t0 < kBlockFrames) ? (T - t0) : kBlockFrames;
@@ -580,24 +594,58 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
 }
 
 // ------------------------------------------------------------- kernel 2
-// log_spec = maximum(log_spec, max - 8.0); (log_spec + 4.0) / 4.0   (HF:160-165)
+// log_spec = maximum(log_spec, max - 8.0); (log_spec + 4.0) / 4.0   (HF:160-165).
+// Kernel 1 already stored g(v) = (v + 4) / 4 and the minimum v of each of its
+// workgroups; g is monotone, so the result is max(stored, g(max - 8)) bit for bit, and
+// a workgroup's (n_mel x 64) tile needs touching only when its minimum is below
+// max - 8.  One workgroup here per workgroup of kernel 1: most exit after 5 loads.
 __global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ out, const unsigned* __restrict__ clip_max,
-                                                    long long per_clip) {
+                                                    const float* __restrict__ block_min, int n_mel, int T) {
   const int b = blockIdx.y;
   const float floor_v = dec_max(clip_max[b]) - 8.0f;
-  float* __restrict__ p = out + (long long)b * per_clip;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if ((per_clip & 3) == 0 && ((reinterpret_cast<uintptr_t>(p) & 15u) == 0)) {
-    f32x4* __restrict__ p4 = reinterpret_cast<f32x4*>(p);
-    for (long long i = i0; i < per_clip / 4; i += stride) {
-      f32x4 v = p4[i];
+  const float* bm = block_min + ((long long)b * gridDim.x + blockIdx.x) * 4;
+  const float lowest = fminf(fminf(bm[0], bm[1]), fminf(bm[2], bm[3]));
+  if (!(lowest < floor_v)) return;
+  const float floor_g = (floor_v + 4.0f) * 0.25f;
+  const int t0 = blockIdx.x * kBlockFrames;
+  const int frames_here = (T - t0 < kBlockFrames) ? (T - t0) : kBlockFrames;
+  float* __restrict__ p = out + (long long)b * n_mel * T + t0;
+  const int tid = threadIdx.x;
+  const bool vec = (T & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
+  if (lowest == -INFINITY) {      // silent tile, left unwritten by kernel 1: every value is max(g(-10), g(max-8))
+    const float c = fmaxf(-1.5f, floor_g);
+    if (vec) {
+      for (int idx = tid; idx < n_mel * (kBlockFrames / 4); idx += 256) {
+        const int mel = idx >> 4, c4 = idx & 15;
+        if (4 * c4 < frames_here) *reinterpret_cast<f32x4*>(p + (long long)mel * T + 4 * c4) = f32x4{c, c, c, c};
+      }
+    } else {
+      for (int idx = tid; idx < n_mel * kBlockFrames; idx += 256) {
+        const int mel = idx >> 6, fb = idx & 63;
+        if (fb < frames_here) p[(long long)mel * T + fb] = c;
+      }
+    }
+    return;
+  }
+  if (vec) {
+    for (int idx = tid; idx < n_mel * (kBlockFrames / 4); idx += 256) {
+      const int mel = idx >> 4, c4 = idx & 15;
+      if (4 * c4 < frames_here) {
+        f32x4* q =reinterpret_cast<f32x4*>(p + (long long)mel * T + 4 * c4);
+        f32x4 v = *q;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = (fmaxf(v[j], floor_v) + 4.0f) * 0.25f;
-      p4[i] = v;
+        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], floor_g);
+        *q = v;
+      }
     }
   } else {
-    for (long long i = i0; i < per_clip; i += stride) p[i] = (fmaxf(p[i], floor_v) + 4.0f) * 0.25f;
+    for (int idx = tid; idx < n_mel * kBlockFrames; idx += 256) {
+      const int mel = idx >> 6, fb = idx & 63;
+      if (fb < frames_here) {
+        float* q = p + (long long)mel * T + fb;
+        *q = fmaxf(*q, floor_g);
+      }
+    }
   }
 }
 
@@ -720,12 +768,10 @@ hipError_t launch_frontend(const FrontArgs& a, int batch, int mode, bool aug, in
   return aug ? launch_k1<8, false, true, 0>(a, batch, stream) : launch_k1<8, false, false, 0>(a, batch, stream);
 }
 
-hipError_t launch_clamp(float* out, const unsigned* clip_max, int batch, long long per_clip, hipStream_t stream) {
-  long long work = (per_clip + 3) / 4;
-  int gx = (int)((work + 256 * 4 - 1) / (256 * 4));
-  if (gx < 1) gx = 1;
-  if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(clamp_kernel, dim3(gx, batch), dim3(256), 0, stream, out, clip_max, per_clip);
+hipError_t launch_clamp(float* out, const unsigned* clip_max, const float* block_min, int batch, int n_mel,
+                        int n_frames, hipStream_t stream) {
+  const dim3 grid((n_frames + kBlockFrames - 1) / kBlockFrames, batch);
+  hipLaunchKernelGGL(clamp_kernel, grid, dim3(256), 0, stream, out, clip_max, block_min, n_mel, n_frames);
   return hipGetLastError();
 }
 
