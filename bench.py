@@ -145,6 +145,11 @@ def main() -> None:
     ap.add_argument("--from-host", action="store_true",
                     help="inputs start in pinned host memory: H2D copies on a second stream, double buffered, "
                          "overlap the kernels (the PCIe-inclusive rate; never the headline value)")
+    ap.add_argument("--augment", action="store_true",
+                    help="BASELINE config 3: the augmentation chain fused into the same launch.  Ranges of "
+                         "configs/augmentation.json with the probabilities of noise / speed / shift / volume forced "
+                         "to 1.0 (shipped: 0.5 / 0 / 0 / 0 and a placeholder noise dir), decisions drawn on the host "
+                         "with random.seed(0) in the reference's order, noise bank = 16 synthetic 10 s clips")
     ap.add_argument("--shard-clips", type=int, default=0,
                     help="BASELINE config 4 instead of the default workload: this many clips in all, contiguous "
                          "shards per rank (wfe_amd.sharded), batches of --batch; use with --n-mel 128")
@@ -213,13 +218,40 @@ def main() -> None:
                               "h2d_GBps": args.batch * N_SAMPLES * 4 * args.steps / el / 1e9}), flush=True)
         return
 
+    step = lambda: fe.logmel(wav, lens, out=out)                          # noqa: E731
+    aug_note = "no augmentation"
+    if args.augment:
+        import random
+        from wfe_amd.augment import AugmentPlanner
+        from wfe_amd.frontend import NoiseBank
+        bank = [(0.05 * np.random.default_rng(9000 + j).standard_normal(10 * SR)).astype(np.float32)
+                for j in range(16)]
+        planner = AugmentPlanner([
+            {"type": "noise", "prob": 1.0, "params": {"min_snr_dB": 10, "max_snr_dB": 50}},
+            {"type": "speed", "prob": 1.0, "params": {"min_speed_rate": 0.9, "max_speed_rate": 1.1, "num_rates": 3}},
+            {"type": "shift", "prob": 1.0, "params": {"min_shift_ms": -5, "max_shift_ms": 5}},
+            {"type": "volume", "prob": 1.0, "params": {"min_gain_dBFS": -15, "max_gain_dBFS": 15}},
+        ], noise_lengths=[len(c) for c in bank])
+        rnd = random.Random(0)
+        host_lens = lens.cpu().tolist()
+        t_plan = time.perf_counter()
+        plans = [planner.draw(n, SR, rnd)[0] for n in host_lens]
+        packed = fe.pack_plans(plans)
+        torch.cuda.synchronize()
+        t_plan = time.perf_counter() - t_plan
+        noise = NoiseBank(bank, device)
+        step = lambda: fe.augment_logmel(wav, lens, packed, noise, out=out)  # noqa: E731
+        aug_note = ("augmentation fused: noise(10..50 dB SNR) -> speed{0.9,1.0,1.1} -> shift[-5,5] ms -> "
+                    "volume[-15,15] dB, probabilities forced to 1.0, op lists resident in HBM "
+                    f"(host draw + pack of one batch: {t_plan * 1e3:.2f} ms, outside the timed region)")
+
     for _ in range(args.warmup):
-        fe.logmel(wav, lens, out=out)
+        step()
     barrier()
     fe.kernel_timing(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        fe.logmel(wav, lens, out=out)
+        step()
     barrier()
     elapsed = time.perf_counter() - t0
     k1_ms, k2_ms, launches = fe.kernel_times()
@@ -258,7 +290,7 @@ def main() -> None:
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"whisper-small {args.n_mel}-mel front end, batch {args.batch} synthetic 30 s "
-                                   "16 kHz clips per GPU, no augmentation, input resident in HBM"
+                                   f"16 kHz clips per GPU, {aug_note}, input resident in HBM"
                                    + ("" if args.lengths == "full" else "; utterances 1..15 s padded to 30 s"),
                        "batch_per_gpu": args.batch, "n_mel": args.n_mel, "clip_seconds": 30,
                        "parallelism": f"dp{world} (utterances sharded, no data-path collective)"},

@@ -157,3 +157,70 @@ def test_do_normalize_affine(fe, golden_logmel):
     keep = cases.kept_frames(3000)
     err = np.abs(got[0].cpu().numpy()[:, keep] - golden_logmel["normalized_test_wav_80"]).max()
     assert err <= 1e-4, err
+
+
+@pytest.mark.parametrize("order", [
+    ("shift", "speed", "noise", "volume"),
+    ("volume", "noise", "shift", "speed", "noise2", "shift2"),
+    ("speed", "shift"),
+    ("noise", "volume", "noise2"),
+])
+def test_other_chain_orders(fe, order):
+    """The kernels evaluate any order of ops around (at most) one speed op: the
+    staged evaluator (two passes through LDS for speed chains) against the CPU
+    oracle, which was pinned on the reference's augment() for the shipped order."""
+    from wfe_amd.frontend import NoiseBank, pack_ragged
+    from wfe_amd.augment import AugmentPlanner
+    entry = {
+        "noise": {"type": "noise", "params": {"min_snr_dB": 10, "max_snr_dB": 50}, "prob": 1.0},
+        "noise2": {"type": "noise", "params": {"min_snr_dB": 0, "max_snr_dB": 20}, "prob": 1.0},
+        "speed": {"type": "speed", "params": {"min_speed_rate": 0.8, "max_speed_rate": 1.3, "num_rates": 6}, "prob": 1.0},
+        "shift": {"type": "shift", "params": {"min_shift_ms": -40, "max_shift_ms": 40}, "prob": 1.0},
+        "shift2": {"type": "shift", "params": {"min_shift_ms": -900, "max_shift_ms": 900}, "prob": 1.0},
+        "volume": {"type": "volume", "params": {"min_gain_dBFS": -15, "max_gain_dBFS": 15}, "prob": 1.0},
+    }
+    cfg = [entry[o] for o in order]
+    bank = [cases.noise_clip(0, 0.7), cases.noise_clip(1, 4.0), cases.noise_clip(2, 12.0)]
+    waves = [cases.bench_clip(10 + i, n) for i, n in enumerate((163840, 30001, 20000, 100000, 52000, 481234))]
+    plans, want = [], []
+    for i, w in enumerate(waves):
+        planner = AugmentPlanner(cfg, [len(b) for b in bank])
+        ops, n_out = planner.draw(len(w), 16000, random.Random(700 + i))
+        aug, _, _ = oa.augment(w.copy(), 16000, cfg, random.Random(700 + i), bank)
+        assert len(aug) == n_out
+        plans.append(ops)
+        want.append(aug)
+    flat, off, lens = pack_ragged(waves, fe.device)
+    nb = NoiseBank(bank, fe.device)
+    n_samples = 200000                          # some utterances truncated, some padded
+    wav, wl = fe.augment_waveform(flat, lens, plans, nb, n_samples=n_samples, offsets=off)
+    got = fe.augment_logmel(flat, lens, plans, nb, n_samples=n_samples, offsets=off)
+    torch.cuda.synchronize()
+    n_noise_ops = sum(o.startswith("noise") for o in order)
+    for i, w in enumerate(want):
+        k = min(len(w), n_samples)
+        assert int(wl[i]) == len(w)
+        err = np.abs(wav[i, :k].cpu().numpy() - w[:k]).max()
+        if n_noise_ops == 0:
+            assert err == 0.0, (i, err)
+        else:
+            assert err <= n_noise_ops * NOISE_RTOL * max(np.abs(w).max(), 1e-30), (i, err)
+        assert not wav[i, k:].any()
+    ref = ol.logmel_f32(want, n_mel=80, n_samples=n_samples)
+    err = np.abs(got.cpu().numpy() - ref).reshape(len(waves), -1).max(axis=1)
+    assert (err <= 1e-4).all(), err
+
+
+@pytest.mark.parametrize("rate", [0.31, 2.9, 7.5, 33.0])
+def test_extreme_speed_rates(fe, rate):
+    """Rates far outside the shipped 0.9..1.1: the source span of a staging pass
+    no longer fits the LDS buffer in one piece (more, smaller passes) and, above
+    ~20x, not at all (per-position evaluation).  Bit-exact against the oracle."""
+    from wfe_amd import _lib
+    w = cases.bench_clip(77, 300000)
+    want = oa.change_speed(w.copy(), rate)
+    got, got_len = _run_wave(fe, [w], [[(_lib.AUG_SPEED, int(len(w) / rate), 0, 0, 0.0)]], n_samples=480000)
+    k = min(len(want), 480000)
+    assert got_len[0] == len(want)
+    assert np.array_equal(got[0, :k], want[:k]), np.abs(got[0, :k] - want[:k]).max()
+    assert not got[0, k:].any()

@@ -33,6 +33,7 @@ struct wfe_context {
   bool timing = false;
   std::vector<hipEvent_t> ev_pool;      // triples: before K1, after K1, after K2
   size_t ev_used = 0;
+  double* d_partials = nullptr;             // resolve pass: per-part sums of the batch slice
   float* d_block_min = nullptr;             // per-wave minima of kernel 1, grows on demand
   size_t block_min_cap = 0;
   unsigned long long* d_stamps = nullptr;   // diagnostic builds only (wfe_debug_stamps)
@@ -126,6 +127,8 @@ int ensure_aug_workspace(wfe_context* h, size_t total_ops, const float* noise, c
     HIP_TRY(h, hipMalloc(&h->d_resolved, cap * sizeof(wfe::Resolved)));
     h->resolved_cap = cap;
   }
+  if (!h->d_partials)
+    HIP_TRY(h, hipMalloc(&h->d_partials, sizeof(double) * 2 * wfe::kResolveParts * kMaxBatchPerLaunch));
   if (n_noise > 0) {
     if ((size_t)n_noise > h->noise_cap) {
       if (h->d_noise_meansq) HIP_TRY(h, hipFree(h->d_noise_meansq));
@@ -188,7 +191,7 @@ int run_frontend(wfe_context* h, const float* wav, const int64_t* offsets, const
       a.noise_off = reinterpret_cast<const long long*>(noise_off);
       a.noise_meansq = h->d_noise_meansq;
       a.resolved = h->d_resolved;
-      HIP_TRY(h, wfe::launch_resolve(a, s.count, stream));
+      HIP_TRY(h, wfe::launch_resolve(a, s.count, h->d_partials, stream));
     }
     // clip maxima of this slice and the per-CU arrival tickets (contiguous): one memset
     if (mode == 0)
@@ -279,6 +282,7 @@ int wfe_destroy(wfe_handle h) {
   if (h->d_resolved) (void)hipFree(h->d_resolved);
   if (h->d_noise_meansq) (void)hipFree(h->d_noise_meansq);
   if (h->d_block_min) (void)hipFree(h->d_block_min);
+  if (h->d_partials) (void)hipFree(h->d_partials);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   delete h;
   return WFE_OK;
@@ -373,7 +377,7 @@ int wfe_augment_waveform(wfe_handle h, const float* wav, const int64_t* offsets,
     a.noise_off = reinterpret_cast<const long long*>(noise_offsets);
     a.noise_meansq = h->d_noise_meansq;
     a.resolved = h->d_resolved;
-    HIP_TRY(h, wfe::launch_resolve(a, s.count, stream));
+    HIP_TRY(h, wfe::launch_resolve(a, s.count, h->d_partials, stream));
     HIP_TRY(h, wfe::launch_waveform(a, s.count, out + (long long)s.begin * n_samples,
                                     out_lengths ? out_lengths + s.begin : nullptr, stream));
   }

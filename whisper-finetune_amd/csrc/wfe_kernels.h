@@ -52,7 +52,9 @@ hipError_t launch_clamp(float* out, const unsigned* clip_max, const float* block
 hipError_t launch_noise_meansq(const float* noise, const long long* noise_off, int n_noise, double* meansq,
                                hipStream_t stream);
 // resolve the data-dependent scalars of every utterance's chain (NOISE gains, AFFINE stats)
-hipError_t launch_resolve(const FrontArgs& a, int batch, hipStream_t stream);
+// partials: workspace of batch x kResolveParts x 2 doubles
+constexpr int kResolveParts = 16;
+hipError_t launch_resolve(const FrontArgs& a, int batch, double* partials, hipStream_t stream);
 // augmented + padded waveform (batch, n_samples) and final lengths
 hipError_t launch_waveform(const FrontArgs& a, int batch, float* out, int* out_lengths, hipStream_t stream);
 

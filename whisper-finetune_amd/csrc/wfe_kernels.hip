@@ -179,6 +179,220 @@ __device__ inline int chain_len(const Chain& c, int n_ops_used) {
   return (c.speed_at >= 0 && c.speed_at < n_ops_used) ? c.len1 : c.len0;
 }
 
+// ---- the same chain, op-major over a register batch (kernel 1's staging).
+// chain_eval above walks one index through the whole chain: every gather waits for
+// the previous one and a sped-up position evaluates seg0 twice.  Here the ops are
+// the OUTER loop and U positions the unrolled inner one, so the U gathers of a
+// NOISE op (and the U raw loads) are in flight together, and a SPEED chain is
+// evaluated in two passes through LDS: seg0 once per SOURCE index into a buffer,
+// then interpolation + seg1 per output position.  Per-position arithmetic is the
+// identical sequence of float32 / float64 roundings.
+constexpr int kDeadIndex = -(1 << 29);       // "not a sample": out of every segment's range, |shift sums| < 2^28
+
+__device__ __forceinline__ int seg_shift_sum(const Chain& c, int lo, int hi) {
+  int s = 0;
+  for (int k = lo; k < hi; ++k)
+    if (c.ops[k].kind == WFE_AUG_SHIFT) s += c.ops[k].i0;
+  return s;
+}
+
+// v[u] = input at cur[u] (0 outside [0, L)); applies ops [lo, hi) in order
+template <int U>
+__device__ __forceinline__ void seg_apply(const Chain& c, int lo, int hi, int L, int (&cur)[U], float (&v)[U]) {
+  for (int k = lo; k < hi; ++k) {
+    const wfe_aug_op op = c.ops[k];
+    if (op.kind == WFE_AUG_VOLUME) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = __fmul_rn(v[u], op.f0);
+    } else if (op.kind == WFE_AUG_SHIFT) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!(cur[u] >= 0 && cur[u] < L)) v[u] = 0.f;
+        cur[u] -= op.i0;
+      }
+    } else if (op.kind == WFE_AUG_NOISE) {
+      const Resolved r = c.res[k];
+      const long long o0 = c.noise_off[op.i0];
+      const int ln = (int)(c.noise_off[op.i0 + 1] - o0);
+      const bool wrap = ln < L;
+      const double inv = ln > 0 ? 1.0 / (double)ln : 0.0;
+      float nz[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool in = cur[u] >= 0 && cur[u] < L && ln > 0;
+        int j = cur[u] + op.i1;
+        if (wrap) {                                   // cur % ln without the integer divide
+          const int qd = (int)((double)cur[u] * inv);
+          j = cur[u] - qd * ln;
+          if (j < 0) j += ln;
+          if (j >= ln) j -= ln;
+        }
+        nz[u] = in ? c.noise[o0 + j] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (cur[u] >= 0 && cur[u] < L && ln > 0) v[u] = __fadd_rn(__fmul_rn(v[u], r.a), __fmul_rn(nz[u], r.b));
+    } else if (op.kind == WFE_AUG_AFFINE) {
+      const Resolved r = c.res[k];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (cur[u] >= 0 && cur[u] < L) v[u] = __fdiv_rn(__fsub_rn(v[u], r.a), r.b);
+    }
+  }
+}
+
+// index into the (truncated, zero-padded, reflect-padded) utterance of staging
+// position q, or -1 where the padded signal is zero
+__device__ __forceinline__ int padded_index(int q, int p0, int n, int len) {
+  int i = p0 + q - kHalf;
+  if (i < 0) i = -i;                    // torch.stft center=True, pad_mode="reflect"
+  if (i >= n) i = 2 * (n - 1) - i;
+  return (q < kBlockSamples && i >= 0 && i < len) ? i : -1;
+}
+
+__device__ __forceinline__ double speed_pos(const Chain& c, int i) {
+  if (c.len1 <= 1) return 0.0;
+  return (i == c.len1 - 1) ? (double)c.len0 : __dmul_rn((double)i, c.step);
+}
+
+// Stages the augmented padded signal of one workgroup into the LDS image.
+// aux: AUXF floats of LDS free during staging (the seg0 buffer of SPEED chains).
+template <int AUXF>
+__device__ inline void stage_augmented(const Chain& c, float* __restrict__ lds, float* __restrict__ aux, int p0, int n,
+                                       int len, int tid) {
+  if (c.speed_at < 0) {
+    constexpr int U = 7;                        // 41 positions per thread in 6 batches of 7
+    const int S = seg_shift_sum(c, 0, c.n_ops);
+    for (int q0 = tid; q0 < kBlockSamples; q0 += 256 * U) {
+      int cur[U];
+      float v[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = padded_index(q0 + 256 * u, p0, n, len);
+        ok[u] = i >= 0;
+        cur[u] = ok[u] ? i + S : kDeadIndex;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = (cur[u] >= 0 && cur[u] < c.len0) ? c.w[cur[u]] : 0.f;
+      seg_apply<U>(c, 0, c.n_ops, c.len0, cur, v);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int q = q0 + 256 * u;
+        if (q < kBlockSamples) lds[pad_q(q)] = ok[u] ? v[u] : 0.f;
+      }
+    }
+    return;
+  }
+
+  constexpr int U = 6;
+  const int S0 = seg_shift_sum(c, 0, c.speed_at);
+  const int S1 = seg_shift_sum(c, c.speed_at + 1, c.n_ops);
+  const int last = c.len0 - 1;
+  // positions per pass: their source span (C - 1) * step + 3 must fit the buffer
+  int C = kBlockSamples;
+  if (c.step > 1.0) {
+    const double fit = (double)(AUXF - 3) / c.step;
+    if (fit < (double)C) C = (int)fit;
+  } else if (C > AUXF - 3) {
+    C = AUXF - 3;
+  }
+  C = C / 256 * 256;
+  for (int qa = 0; qa < kBlockSamples; qa += (C > 0 ? C : kBlockSamples)) {
+    const int qb = (C > 0 && qa + C < kBlockSamples) ? qa + C : kBlockSamples;
+    // hull of the utterance indices the positions [qa, qb) map to (reflections fold, never stretch)
+    int lo_i = p0 + qa - kHalf, hi_i = p0 + qb - 1 - kHalf;
+    if (hi_i < 0) {
+      const int t = -hi_i;
+      hi_i = -lo_i;
+      lo_i = t;
+    } else if (lo_i < 0) {
+      hi_i = (-lo_i > hi_i) ? -lo_i : hi_i;
+      lo_i = 0;
+    }
+    if (lo_i >= n) {
+      const int t = 2 * (n - 1) - hi_i;
+      hi_i = 2 * (n - 1) - lo_i;
+      lo_i = t;
+    } else if (hi_i >= n) {
+      const int t = 2 * (n - 1) - hi_i;
+      lo_i = t < lo_i ? t : lo_i;
+      hi_i = n - 1;
+    }
+    if (lo_i < 0) lo_i = 0;
+    if (hi_i > len - 1) hi_i = len - 1;
+    int cmin = lo_i + S1, cmax = hi_i + S1;            // indices into the sped-up signal
+    if (cmin < 0) cmin = 0;
+    if (cmax > c.len1 - 1) cmax = c.len1 - 1;
+    const bool any = lo_i <= hi_i && cmin <= cmax && last >= 0;
+    int jlo = 0, jhi = -1;
+    if (any) {
+      const double plo = speed_pos(c, cmin), phi = speed_pos(c, cmax);
+      jlo = plo >= (double)last ? last : (int)plo;
+      jhi = phi >= (double)last ? last : (int)phi + 1;
+      if (jhi > last) jhi = last;
+    }
+    const bool buffered = C > 0 && jhi - jlo + 1 <= AUXF;
+    if (buffered) {
+      // pass A: seg0 at every source index of the span, once
+      for (int j0 = jlo + tid; j0 <= jhi; j0 += 256 * U) {
+        int cur[U];
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = (j0 + 256 * u <= jhi) ? j0 + 256 * u + S0 : kDeadIndex;
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = (cur[u] >= 0 && cur[u] < c.len0) ? c.w[cur[u]] : 0.f;
+        seg_apply<U>(c, 0, c.speed_at, c.len0, cur, v);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (j0 + 256 * u <= jhi) aux[j0 + 256 * u - jlo] = v[u];
+      }
+    }
+    __syncthreads();
+    // pass B: np.interp in float64 between two buffered seg0 values, then seg1
+    for (int q0 = qa + tid; q0 < qb; q0 += 256 * U) {
+      int cur[U];
+      float v[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int q = q0 + 256 * u;
+        const int i = (q < qb) ? padded_index(q, p0, n, len) : -1;
+        ok[u] = i >= 0;
+        cur[u] = ok[u] ? i + S1 : kDeadIndex;
+        float x = 0.f;
+        if (cur[u] >= 0 && cur[u] < c.len1) {
+          if (buffered) {
+            const double pos = speed_pos(c, cur[u]);
+            // (indices are inside [jlo, jhi] by construction; the clamps keep a
+            // mistake in the hull above a wrong value instead of a stray LDS access)
+            auto at = [&](int j) { return aux[min(max(j - jlo, 0), AUXF - 1)]; };
+            if (pos >= (double)last) {
+              x = at(last);
+            } else {
+              const int j = (int)pos;
+              const double a0 = (double)at(j);
+              const double fr = pos - (double)j;
+              const double a1 = (double)at(j + 1 <= jhi ? j + 1 : jhi);
+              x = (fr == 0.0) ? (float)a0 : (float)__dadd_rn(__dmul_rn(a1 - a0, fr), a0);
+            }
+          } else {
+            x = speed_eval(c, cur[u]);          // span too wide for the buffer (speed rate > ~20)
+          }
+        }
+        v[u] = x;
+      }
+      seg_apply<U>(c, c.speed_at + 1, c.n_ops, c.len1, cur, v);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int q = q0 + 256 * u;
+        if (q < qb) lds[pad_q(q)] = ok[u] ? v[u] : 0.f;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------- kernel 1
 template <int NMT, bool POWER, bool AUG, int BANK>
 __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
@@ -280,6 +494,9 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   {
     const bool interior = !AUG && i_first >= 0 && i_first + kBlockSamples <= len &&
                           ((reinterpret_cast<uintptr_t>(w + i_first) & 15u) == 0);
+    if (AUG) {
+      stage_augmented<kAuxFloats>(c, lds, lds + kLdsWaveFloats, p0, n, len, tid);
+    } else
     if (interior) {
       // every load in flight before the first LDS write: one HBM round trip per tile
       const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(w + i_first);
@@ -313,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
           if (i < 0) i = -i;                    // torch.stft center=True, pad_mode="reflect"
           if (i >= n) i = 2 * (n - 1) - i;
           float v = 0.f;                        // right zero padding (padding_value 0.0)
-          if (q < kBlockSamples && i >= 0 && i < len) v = AUG ? chain_eval(c, c.n_ops, i) : w[i];
+          if (q < kBlockSamples && i >= 0 && i < len) v = w[i];
           vals[u] = v;
         }
 #pragma unroll
@@ -681,11 +898,71 @@ __global__ __launch_bounds__(1024) void noise_meansq_kernel(const float* __restr
 // rms_db (utils/reader.py:350-353) under NumPy-2 float32 scalar semantics
 __device__ inline float rms_db_f32(double meansq) { return __fmul_rn(10.0f, log10f((float)meansq)); }
 
+// Statistics of the signal ENTERING the first NOISE / AFFINE op of every utterance
+// (the only one in the reference's configurations), kResolveParts workgroups per
+// utterance so that the pass runs at HBM rate: float64 partial sums of x and x*x
+// over a fixed partition, combined in a fixed order by resolve_kernel (the result
+// does not depend on scheduling).
+__device__ inline int first_resolvable(const Chain& c) {
+  for (int k = 0; k < c.n_ops; ++k)
+    if (c.ops[k].kind == WFE_AUG_NOISE || c.ops[k].kind == WFE_AUG_AFFINE) return k;
+  return -1;
+}
+
+__global__ __launch_bounds__(256) void resolve_partial_kernel(const FrontArgs a, double* __restrict__ partials) {
+  __shared__ double sh[4];
+  const int b = blockIdx.y, part = blockIdx.x;
+  const float* w = a.wav + (a.offsets ? a.offsets[b] : (long long)b * a.row_stride);
+  int raw_len = a.lengths[b];
+  if (raw_len < 0) raw_len = 0;
+  const Chain c = make_chain(a, b, w, raw_len);
+  const int k0 = first_resolvable(c);
+  if (k0 < 0) return;
+  int L = chain_len(c, k0);
+  if (c.ops[k0].kind == WFE_AUG_AFFINE && L > a.n_samples) L = a.n_samples;
+  const int per = (L + kResolveParts - 1) / kResolveParts;
+  const int lo = part * per, hi = (lo + per < L) ? lo + per : L;
+  double s1 = 0.0, s2 = 0.0;
+  if (c.speed_at < 0 || c.speed_at >= k0) {
+    constexpr int U = 8;
+    const int S = seg_shift_sum(c, 0, k0);
+    for (int i0 = lo + (int)threadIdx.x; i0 < hi; i0 += 256 * U) {
+      int cur[U];
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) cur[u] = (i0 + 256 * u < hi) ? i0 + 256 * u + S : kDeadIndex;
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = (cur[u] >= 0 && cur[u] < c.len0) ? w[cur[u]] : 0.f;
+      seg_apply<U>(c, 0, k0, c.len0, cur, v);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (i0 + 256 * u < hi) {
+          s1 += (double)v[u];
+          s2 += (double)__fmul_rn(v[u], v[u]);         // float32 squares, as sample ** 2
+        }
+    }
+  } else {
+    for (int i = lo + (int)threadIdx.x; i < hi; i += 256) {
+      const float x = chain_eval(c, k0, i);
+      s1 += (double)x;
+      s2 += (double)__fmul_rn(x, x);
+    }
+  }
+  s1 = block_sum<256>(s1, sh);
+  s2 = block_sum<256>(s2, sh);
+  if (threadIdx.x == 0) {
+    partials[((long long)b * kResolveParts + part) * 2 + 0] = s1;
+    partials[((long long)b * kResolveParts + part) * 2 + 1] = s2;
+  }
+}
+
 // One workgroup per utterance: walks its chain in order and fills the
 // data-dependent scalars of NOISE (gains, utils/reader.py:325-331) and AFFINE
 // (mean / std, HF:172-191) ops.  An op's statistics are taken over the signal
 // ENTERING it, so earlier ops -- including earlier resolved ones -- are applied.
-__global__ __launch_bounds__(1024) void resolve_kernel(const FrontArgs a) {
+// The first such op takes its sums from resolve_partial_kernel; any later one is
+// summed here.
+__global__ __launch_bounds__(1024) void resolve_kernel(const FrontArgs a, const double* __restrict__ partials) {
   __shared__ double sh[16];
   const int b = blockIdx.x;
   const float* w = a.wav + (a.offsets ? a.offsets[b] : (long long)b * a.row_stride);
@@ -693,19 +970,28 @@ __global__ __launch_bounds__(1024) void resolve_kernel(const FrontArgs a) {
   if (raw_len < 0) raw_len = 0;
   const Chain c = make_chain(a, b, w, raw_len);
   Resolved* res = a.resolved + a.op_begin[b];
+  bool first = true;
   for (int k = 0; k < c.n_ops; ++k) {
     const int kind = c.ops[k].kind;
     if (kind != WFE_AUG_NOISE && kind != WFE_AUG_AFFINE) continue;
     int L = chain_len(c, k);
     if (kind == WFE_AUG_AFFINE && L > a.n_samples) L = a.n_samples;   // stats over the kept prefix
     double s1 = 0.0, s2 = 0.0;
-    for (int i = threadIdx.x; i < L; i += 1024) {
-      const float x = chain_eval(c, k, i);
-      s1 += (double)x;
-      s2 += (double)__fmul_rn(x, x);
+    if (first) {
+      for (int p = 0; p < kResolveParts; ++p) {
+        s1 += partials[((long long)b * kResolveParts + p) * 2 + 0];
+        s2 += partials[((long long)b * kResolveParts + p) * 2 + 1];
+      }
+    } else {
+      for (int i = threadIdx.x; i < L; i += 1024) {
+        const float x = chain_eval(c, k, i);
+        s1 += (double)x;
+        s2 += (double)__fmul_rn(x, x);
+      }
+      s1 = block_sum<1024>(s1, sh);
+      s2 = block_sum<1024>(s2, sh);
     }
-    s1 = block_sum<1024>(s1, sh);
-    s2 = block_sum<1024>(s2, sh);
+    first = false;
     if (threadIdx.x == 0) {
       Resolved r{0.f, 1.f};
       if (kind == WFE_AUG_NOISE) {
@@ -731,8 +1017,14 @@ __global__ __launch_bounds__(1024) void resolve_kernel(const FrontArgs a) {
   }
 }
 
+// The augmented waveform itself (stage-level parity tests).  It runs kernel 1's own
+// staging code, stage_augmented, over the same 10480-position spans and copies the
+// LDS image out, so the bit-exact waveform tests exercise the production evaluator.
 __global__ __launch_bounds__(256) void waveform_kernel(const FrontArgs a, float* __restrict__ out,
                                                        int* __restrict__ out_len) {
+  constexpr int kAux = 2 * kDftStepFloats;
+  constexpr int kSpan = kBlockFrames * kHop;            // output samples per workgroup (10240)
+  __shared__ __attribute__((aligned(16))) float lds[kLdsWaveFloats + kAux];
   const int b = blockIdx.y;
   const float* w = a.wav + (a.offsets ? a.offsets[b] : (long long)b * a.row_stride);
   int raw_len = a.lengths[b];
@@ -741,9 +1033,14 @@ __global__ __launch_bounds__(256) void waveform_kernel(const FrontArgs a, float*
   const int L = chain_len(c, c.n_ops);
   const int keep = L < a.n_samples ? L : a.n_samples;
   if (blockIdx.x == 0 && threadIdx.x == 0 && out_len) out_len[b] = L;
+  const int p0 = blockIdx.x * kSpan;                    // staging position q holds sample p0 + q - 200
+  stage_augmented<kAux>(c, lds, lds + kLdsWaveFloats, p0, a.n_samples, keep, threadIdx.x);
+  __syncthreads();
   float* o = out + (long long)b * a.n_samples;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n_samples; i += gridDim.x * 256)
-    o[i] = i < keep ? chain_eval(c, c.n_ops, i) : 0.f;
+  for (int q = kHalf + threadIdx.x; q < kHalf + kSpan; q += 256) {
+    const int i = p0 + q - kHalf;
+    if (i < a.n_samples) o[i] = lds[pad_q(q)];
+  }
 }
 
 // ------------------------------------------------------------- launchers
@@ -782,16 +1079,17 @@ hipError_t launch_noise_meansq(const float* noise, const long long* off, int n_n
   return hipGetLastError();
 }
 
-hipError_t launch_resolve(const FrontArgs& a, int batch, hipStream_t stream) {
-  hipLaunchKernelGGL(resolve_kernel, dim3(batch), dim3(1024), 0, stream, a);
+hipError_t launch_resolve(const FrontArgs& a, int batch, double* partials, hipStream_t stream) {
+  hipLaunchKernelGGL(resolve_partial_kernel, dim3(kResolveParts, batch), dim3(256), 0, stream, a, partials);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(resolve_kernel, dim3(batch), dim3(1024), 0, stream, a, partials);
   return hipGetLastError();
 }
 
 hipError_t launch_waveform(const FrontArgs& a, int batch, float* out, int* out_lengths, hipStream_t stream) {
-  int gx = (a.n_samples + 256 * 8 - 1) / (256 * 8);
-  if (gx < 1) gx = 1;
-  if (gx > 128) gx = 128;
-  hipLaunchKernelGGL(waveform_kernel, dim3(gx, batch), dim3(256), 0, stream, a, out, out_lengths);
+  const int gx = (a.n_samples + kBlockFrames * kHop - 1) / (kBlockFrames * kHop);
+  hipLaunchKernelGGL(waveform_kernel, dim3(gx < 1 ? 1 : gx, batch), dim3(256), 0, stream, a, out, out_lengths);
   return hipGetLastError();
 }
 

@@ -130,28 +130,39 @@ class HipFrontEnd:
         return out
 
     # ------------------------------------------------------------ augmentation
-    def _pack_ops(self, plans: Sequence[Sequence[tuple]]):
-        """plans[b] = list of (kind, i0, i1, i2, f0) -> device arrays."""
-        total = sum(len(p) for p in plans)
-        arr = (_lib.WfeAugOp * max(total, 1))()
+    _OP_DTYPE = np.dtype([("kind", "<i4"), ("i0", "<i4"), ("i1", "<i4"), ("i2", "<i4"),
+                          ("f0", "<f4"), ("f1", "<f4"), ("d0", "<f8")])     # == wfe_aug_op, 32 bytes
+
+    def pack_plans(self, plans: Sequence[Sequence[tuple]]):
+        """plans[b] = list of (kind, i0, i1, i2, f0) -> (device op array, device op_begin,
+        total): the arguments of wfe_augment_logmel.  The result may be passed to
+        augment_logmel / augment_waveform in place of ``plans``."""
+        counts = np.fromiter((len(p) for p in plans), dtype=np.int64, count=len(plans))
+        total = int(counts.sum())
+        arr = np.zeros(max(total, 1), dtype=self._OP_DTYPE)
+        if total:
+            flat = [op for plan in plans for op in plan]
+            arr["kind"][:total] = [o[0] for o in flat]
+            arr["i0"][:total] = [o[1] for o in flat]
+            arr["i1"][:total] = [o[2] for o in flat]
+            arr["i2"][:total] = [o[3] for o in flat]
+            arr["f0"][:total] = [o[4] for o in flat]
         begin = np.zeros(len(plans) + 1, dtype=np.int32)
-        k = 0
-        for b, plan in enumerate(plans):
-            begin[b] = k
-            for (kind, i0, i1, i2, f0) in plan:
-                arr[k] = _lib.WfeAugOp(int(kind), int(i0), int(i1), int(i2), float(f0), 0.0, 0.0)
-                k += 1
-        begin[len(plans)] = k
-        raw = np.frombuffer(arr, dtype=np.uint8).copy()
-        return torch.from_numpy(raw).to(self.device), torch.from_numpy(begin).to(self.device), total
+        np.cumsum(counts, out=begin[1:])
+        return (torch.from_numpy(arr.view(np.uint8)).to(self.device), torch.from_numpy(begin).to(self.device), total)
+
+    def _pack_ops(self, plans):
+        if isinstance(plans, tuple) and len(plans) == 3 and isinstance(plans[0], torch.Tensor):
+            return plans
+        return self.pack_plans(plans)
 
     def augment_logmel(self, wav, lengths, plans, noise: Optional[NoiseBank] = None, n_samples: int = N_SAMPLES,
                        offsets=None, out=None) -> torch.Tensor:
         batch, stride = self._geometry(wav, lengths, offsets)
         self._check_inputs(wav, lengths, offsets, batch)
-        if len(plans) != batch:
-            raise ValueError("one op list per utterance")
         ops, begin, total = self._pack_ops(plans)
+        if begin.numel() != batch + 1:
+            raise ValueError("one op list per utterance")
         shape = (batch, self.n_mel, n_samples // HOP)
         if out is None:
             out = torch.empty(shape, dtype=torch.float32, device=self.device)
