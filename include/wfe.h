@@ -119,6 +119,23 @@ int wfe_augment_logmel(wfe_handle h, const float* wav, const int64_t* offsets, c
                        const float* noise, const int64_t* noise_offsets, int32_t n_noise,
                        float* out, void* stream);
 
+/* The same two calls on 16-bit PCM as it lies in a WAV file, replacing the
+ * decode-to-float32 and mono mix-down of CustomDataset._get_list_data
+ * (utils/reader.py:144 soundfile.read(dtype='float32'), :148-150 librosa.to_mono):
+ * sample = pcm / 32768 (exact), mono = float32 mean over the `channels`
+ * interleaved values of a frame.  Halves the host-to-device bytes and removes the
+ * host conversion pass.
+ *   pcm        device int16, interleaved.  Utterance b starts at pcm + offsets[b]
+ *              or pcm + b*row_stride (both counted in int16 ELEMENTS).
+ *   lengths    FRAMES (samples per channel) of each utterance.
+ *   channels   1..256, the same for the whole batch.
+ * ops == NULL (then op_begin, noise are ignored) runs without augmentation. */
+int wfe_logmel_pcm16(wfe_handle h, const int16_t* pcm, const int64_t* offsets, const int32_t* lengths,
+                     int64_t row_stride, int32_t channels, int32_t batch, int32_t n_samples,
+                     const wfe_aug_op* ops, const int32_t* op_begin, int64_t total_ops,
+                     const float* noise, const int64_t* noise_offsets, int32_t n_noise,
+                     float* out, void* stream);
+
 /* The augmented, padded waveform itself, (batch, n_samples) float32: what
  * CustomDataset._get_list_data returns (utils/reader.py:134-162) after pad/trim.
  * Used by the parity tests of the augmentation stages. */

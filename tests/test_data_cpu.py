@@ -42,9 +42,10 @@ def corpus(tmp_path):
     return str(mf), recs
 
 
-def test_manifest_filter_and_items(corpus):
+def test_manifest_filter_and_items(corpus, monkeypatch):
     mf, recs = corpus
     proc = stubs.StubProcessor()
+    monkeypatch.setenv("WFE_PCM16", "0")                  # float32 host decode, as the reference (reader.py:144)
     ds = wd.CustomDataset(mf, proc)
     assert len(ds) == 3                                   # 0.3 s (< min) and 31 s (> max) dropped (reader.py:127-130)
     it = ds[0]
@@ -56,6 +57,49 @@ def test_manifest_filter_and_items(corpus):
     assert it["waveform"].shape == (12000,) and it["labels"][1] == stubs.ZH
     batch = ds.__getitems__([0, 1, 2])                    # threaded decode path gives the same items
     assert all(np.array_equal(a["waveform"], ds[i]["waveform"]) for i, a in enumerate(batch))
+
+
+def test_pcm16_items_are_the_file_samples(corpus, tmp_path, monkeypatch):
+    """Default decode of 16-bit PCM: the int16 samples as they lie in the file
+    (frames, channels); x / 32768 and the mono mean happen on the GPU.  Here: the
+    values equal the float32 decode times 32768, slices agree, a stereo file stays
+    interleaved, a non-16-bit file falls back to float32."""
+    from wfe_amd.frontend import RaggedPacker
+    mf, recs = corpus
+    proc = stubs.StubProcessor()
+    ds16 = wd.CustomDataset(mf, proc)
+    monkeypatch.setenv("WFE_PCM16", "0")
+    ds32 = wd.CustomDataset(mf, proc)
+    for i in range(3):
+        a, b = ds16[i], ds32[i]
+        assert isinstance(a["waveform"], wd.PcmRef)
+        assert a["waveform"].dtype == np.int16 and a["waveform"].shape == (len(b["waveform"]), 1)
+        assert np.array_equal(a["waveform"][:, 0].astype(np.float32) / np.float32(32768), b["waveform"])
+        assert a["labels"] == b["labels"] and a["id"] == b["id"]
+    st = tmp_path / "st.wav"
+    rng = np.random.default_rng(5)
+    pcm = rng.integers(-32768, 32767, size=(8000, 2), dtype=np.int16)
+    with wave.open(str(st), "wb") as w:
+        w.setnchannels(2)
+        w.setsampwidth(2)
+        w.setframerate(16000)
+        w.writeframes(pcm.tobytes())
+    got, sr = wd.read_pcm16(str(st))
+    assert sr == 16000 and got.shape == (8000, 2) and np.array_equal(np.asarray(got), pcm)
+    got, _ = wd.read_pcm16(str(st), 0.1, -0.1)             # negative end counts from the end (reader.py:229-232)
+    assert np.array_equal(np.asarray(got), pcm[1600:6400])
+    dst = np.full(4800 * 2 + 3, 7, dtype=np.int16)          # read_into fills exactly frames * channels elements
+    got.read_into(dst[:9600])
+    assert np.array_equal(dst[:9600], pcm[1600:6400].reshape(-1)) and (dst[9600:] == 7).all()
+    ref, _ = wd.read_audio(str(st))
+    assert np.array_equal(RaggedPacker._as_float_mono(pcm), np.mean(ref.T, axis=0))
+    b8 = tmp_path / "b8.wav"
+    with wave.open(str(b8), "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(1)
+        w.setframerate(16000)
+        w.writeframes(bytes(range(200)))
+    assert wd.read_pcm16(str(b8)) is None and wd.read_pcm16(str(tmp_path / "missing.wav")) is None
 
 
 def test_timestamp_labels(corpus):

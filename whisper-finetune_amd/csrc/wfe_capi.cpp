@@ -75,7 +75,7 @@ struct DeviceGuard {
   }
 };
 
-int check_common(wfe_context* h, const float* wav, const int32_t* lengths, int32_t batch, int32_t n_samples,
+int check_common(wfe_context* h, const void* wav, const int32_t* lengths, int32_t batch, int32_t n_samples,
                  const void* out) {
   if (!h) return fail(nullptr, WFE_ERR_ARG, "null handle");
   if (batch < 0) return fail(h, WFE_ERR_ARG, "batch %d < 0", batch);
@@ -87,10 +87,17 @@ int check_common(wfe_context* h, const float* wav, const int32_t* lengths, int32
   return WFE_OK;
 }
 
-void fill_args(wfe_context* h, wfe::FrontArgs& a, const float* wav, const int64_t* offsets, const int32_t* lengths,
-               int64_t row_stride, int32_t n_samples) {
+// wav_or_pcm: float32 samples when channels == 0, interleaved int16 otherwise
+void fill_args(wfe_context* h, wfe::FrontArgs& a, const void* wav_or_pcm, int channels, const int64_t* offsets,
+               const int32_t* lengths, int64_t row_stride, int32_t n_samples) {
   std::memset(&a, 0, sizeof a);
-  a.wav = wav;
+  if (channels > 0) {
+    a.pcm = static_cast<const short*>(wav_or_pcm);
+    a.channels = channels;
+  } else {
+    a.wav = static_cast<const float*>(wav_or_pcm);
+    a.channels = 1;
+  }
   a.offsets = reinterpret_cast<const long long*>(offsets);
   a.lengths = lengths;
   a.row_stride = row_stride;
@@ -147,8 +154,8 @@ int ensure_aug_workspace(wfe_context* h, size_t total_ops, const float* noise, c
   return WFE_OK;
 }
 
-int run_frontend(wfe_context* h, const float* wav, const int64_t* offsets, const int32_t* lengths, int64_t row_stride,
-                 int32_t batch, int32_t n_samples, const wfe_aug_op* ops, const int32_t* op_begin, int64_t total_ops,
+int run_frontend(wfe_context* h, const void* wav, int channels, const int64_t* offsets, const int32_t* lengths,
+                 int64_t row_stride, int32_t batch, int32_t n_samples, const wfe_aug_op* ops, const int32_t* op_begin, int64_t total_ops,
                  const float* noise, const int64_t* noise_off, int32_t n_noise, float* out, int mode, void* stream_) {
   int rc = check_common(h, wav, lengths, batch, n_samples, out);
   if (rc != WFE_OK) return rc;
@@ -179,9 +186,11 @@ int run_frontend(wfe_context* h, const float* wav, const int64_t* offsets, const
   const long long per_clip = (mode == 1) ? (long long)wfe::kNfreq * T : (long long)h->cfg.n_mel * T;
   for (const Slice& s : slices(batch)) {
     wfe::FrontArgs a;
-    fill_args(h, a, wav, offsets, lengths, row_stride, n_samples);
+    fill_args(h, a, wav, channels, offsets, lengths, row_stride, n_samples);
     // slice by pointer arithmetic so that blockIdx.y indexes the slice
-    if (offsets) a.offsets += s.begin; else a.wav += (long long)s.begin * row_stride;
+    if (offsets) a.offsets += s.begin;
+    else if (a.pcm) a.pcm += (long long)s.begin * row_stride;
+    else a.wav += (long long)s.begin * row_stride;
     a.lengths += s.begin;
     a.out = out + (long long)s.begin * per_clip;
     if (aug) {
@@ -333,14 +342,14 @@ int wfe_kernel_times(wfe_handle h, double* frontend_ms, double* clamp_ms, int64_
 
 int wfe_logmel(wfe_handle h, const float* wav, const int64_t* offsets, const int32_t* lengths, int64_t row_stride,
                int32_t batch, int32_t n_samples, float* out, void* stream) {
-  return run_frontend(h, wav, offsets, lengths, row_stride, batch, n_samples, nullptr, nullptr, 0, nullptr, nullptr, 0,
-                      out, 0, stream);
+  return run_frontend(h, wav, 0, offsets, lengths, row_stride, batch, n_samples, nullptr, nullptr, 0, nullptr, nullptr,
+                      0, out, 0, stream);
 }
 
 int wfe_power_spectrum(wfe_handle h, const float* wav, const int64_t* offsets, const int32_t* lengths,
                        int64_t row_stride, int32_t batch, int32_t n_samples, float* out, void* stream) {
-  return run_frontend(h, wav, offsets, lengths, row_stride, batch, n_samples, nullptr, nullptr, 0, nullptr, nullptr, 0,
-                      out, 1, stream);
+  return run_frontend(h, wav, 0, offsets, lengths, row_stride, batch, n_samples, nullptr, nullptr, 0, nullptr, nullptr,
+                      0, out, 1, stream);
 }
 
 int wfe_augment_logmel(wfe_handle h, const float* wav, const int64_t* offsets, const int32_t* lengths,
@@ -348,7 +357,18 @@ int wfe_augment_logmel(wfe_handle h, const float* wav, const int64_t* offsets, c
                        const int32_t* op_begin, int64_t total_ops, const float* noise, const int64_t* noise_offsets,
                        int32_t n_noise, float* out, void* stream) {
   if (h && (!ops || !op_begin)) return fail(h, WFE_ERR_ARG, "ops / op_begin must not be null");
-  return run_frontend(h, wav, offsets, lengths, row_stride, batch, n_samples, ops, op_begin, total_ops, noise,
+  return run_frontend(h, wav, 0, offsets, lengths, row_stride, batch, n_samples, ops, op_begin, total_ops, noise,
+                      noise_offsets, n_noise, out, 0, stream);
+}
+
+int wfe_logmel_pcm16(wfe_handle h, const int16_t* pcm, const int64_t* offsets, const int32_t* lengths,
+                     int64_t row_stride, int32_t channels, int32_t batch, int32_t n_samples, const wfe_aug_op* ops,
+                     const int32_t* op_begin, int64_t total_ops, const float* noise, const int64_t* noise_offsets,
+                     int32_t n_noise, float* out, void* stream) {
+  if (h && (channels < 1 || channels > 256)) return fail(h, WFE_ERR_ARG, "channels %d outside 1..256", channels);
+  if (!ops) return run_frontend(h, pcm, channels, offsets, lengths, row_stride, batch, n_samples, nullptr, nullptr, 0,
+                                nullptr, nullptr, 0, out, 0, stream);
+  return run_frontend(h, pcm, channels, offsets, lengths, row_stride, batch, n_samples, ops, op_begin, total_ops, noise,
                       noise_offsets, n_noise, out, 0, stream);
 }
 
@@ -368,7 +388,7 @@ int wfe_augment_waveform(wfe_handle h, const float* wav, const int64_t* offsets,
   if (rc != WFE_OK) return rc;
   for (const Slice& s : slices(batch)) {
     wfe::FrontArgs a;
-    fill_args(h, a, wav, offsets, lengths, row_stride, n_samples);
+    fill_args(h, a, wav, 0, offsets, lengths, row_stride, n_samples);
     if (offsets) a.offsets += s.begin; else a.wav += (long long)s.begin * row_stride;
     a.lengths += s.begin;
     a.ops = ops;

@@ -17,7 +17,9 @@ struct Resolved {
 
 struct FrontArgs {
   // input
-  const float* wav;
+  const float* wav;              // float32 samples, or
+  const short* pcm;              // interleaved 16-bit PCM (then wav is null); offsets / row_stride in int16 elements
+  int channels;                  // PCM only: channels per frame, mixed down to mono (np.mean)
   const long long* offsets;      // optional
   const int* lengths;
   long long row_stride;

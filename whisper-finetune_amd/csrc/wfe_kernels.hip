@@ -83,11 +83,37 @@ __device__ __forceinline__ float dec_max(unsigned k) {
 // (utils/reader.py:281-340) as a pull-style evaluator: value of the augmented
 // signal at one index.  A chain is  seg0 [SPEED seg1]  where seg* hold only
 // index-preserving ops (VOLUME, NOISE, AFFINE) and SHIFT.
+// Where an utterance's samples come from: float32, or interleaved 16-bit PCM
+// converted exactly as soundfile.read(dtype='float32') (x / 32768, a power of two)
+// and mixed down exactly as librosa.to_mono (np.mean over channels in float32:
+// the sum of <= 256 such values is exact, then one float32 division).
+struct Source {
+  const float* w;
+  const short* pcm;
+  int ch;
+  __device__ __forceinline__ float at(int i) const {
+    if (!pcm) return w[i];
+    constexpr float kScale = 1.0f / 32768.0f;
+    if (ch == 1) return (float)pcm[i] * kScale;
+    int t = 0;
+    for (int cc = 0; cc < ch; ++cc) t += pcm[(long long)i * ch + cc];
+    return __fdiv_rn((float)t * kScale, (float)ch);
+  }
+};
+__device__ __forceinline__ Source make_source(const FrontArgs& a, int b) {
+  const long long o = a.offsets ? a.offsets[b] : (long long)b * a.row_stride;
+  Source s;
+  s.w = a.pcm ? nullptr : a.wav + o;
+  s.pcm = a.pcm ? a.pcm + o : nullptr;
+  s.ch = a.channels;
+  return s;
+}
+
 struct Chain {
   const wfe_aug_op* ops;
   const Resolved* res;
   int n_ops;
-  const float* w;
+  Source src;
   int len0;          // raw length
   int len1;          // length after the SPEED op (== len0 when there is none)
   int speed_at;      // index of the SPEED op or -1
@@ -96,13 +122,13 @@ struct Chain {
   const long long* noise_off;
 };
 
-__device__ inline Chain make_chain(const FrontArgs& a, int b, const float* w, int raw_len) {
+__device__ inline Chain make_chain(const FrontArgs& a, int b, const Source& src, int raw_len) {
   Chain c;
   const int lo = a.op_begin[b], hi = a.op_begin[b + 1];
   c.ops = a.ops + lo;
   c.res = a.resolved + lo;
   c.n_ops = hi - lo;
-  c.w = w;
+  c.src = src;
   c.len0 = raw_len;
   c.len1 = raw_len;
   c.speed_at = -1;
@@ -152,7 +178,7 @@ __device__ inline float seg_eval(const Chain& c, int lo, int hi, int L, int idx,
 
 // np.interp(np.linspace(0, len0, len1), arange(len0), seg0)[i] -> float32
 __device__ inline float speed_eval(const Chain& c, int i) {
-  auto raw = [&](int j) { return c.w[j]; };
+  auto raw = [&](int j) { return c.src.at(j); };
   auto s0 = [&](int j) { return seg_eval(c, 0, c.speed_at, c.len0, j, raw); };
   double pos = 0.0;
   if (c.len1 > 1) pos = (i == c.len1 - 1) ? (double)c.len0 : __dmul_rn((double)i, c.step);
@@ -169,7 +195,7 @@ __device__ inline float speed_eval(const Chain& c, int i) {
 // value of the signal after the first n_ops_used ops at index i
 __device__ inline float chain_eval(const Chain& c, int n_ops_used, int i) {
   if (c.speed_at < 0 || c.speed_at >= n_ops_used) {
-    auto raw = [&](int j) { return c.w[j]; };
+    auto raw = [&](int j) { return c.src.at(j); };
     return seg_eval(c, 0, n_ops_used, c.len0, i, raw);
   }
   auto sp = [&](int j) { return speed_eval(c, j); };
@@ -274,7 +300,7 @@ __device__ inline void stage_augmented(const Chain& c, float* __restrict__ lds, 
         cur[u] = ok[u] ? i + S : kDeadIndex;
       }
 #pragma unroll
-      for (int u = 0; u < U; ++u) v[u] = (cur[u] >= 0 && cur[u] < c.len0) ? c.w[cur[u]] : 0.f;
+      for (int u = 0; u < U; ++u) v[u] = (cur[u] >= 0 && cur[u] < c.len0) ? c.src.at(cur[u]) : 0.f;
       seg_apply<U>(c, 0, c.n_ops, c.len0, cur, v);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -341,7 +367,7 @@ __device__ inline void stage_augmented(const Chain& c, float* __restrict__ lds, 
 #pragma unroll
         for (int u = 0; u < U; ++u) cur[u] = (j0 + 256 * u <= jhi) ? j0 + 256 * u + S0 : kDeadIndex;
 #pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = (cur[u] >= 0 && cur[u] < c.len0) ? c.w[cur[u]] : 0.f;
+        for (int u = 0; u < U; ++u) v[u] = (cur[u] >= 0 && cur[u] < c.len0) ? c.src.at(cur[u]) : 0.f;
         seg_apply<U>(c, 0, c.speed_at, c.len0, cur, v);
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -407,14 +433,15 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   const int t0 = blockIdx.x * kBlockFrames;
   const int n = a.n_samples;
   const int T = a.n_frames;
-  const float* __restrict__ w = a.wav + (a.offsets ? a.offsets[b] : (long long)b * a.row_stride);
+  const Source src = make_source(a, b);
+  const float* __restrict__ w = src.w;
   int raw_len = a.lengths[b];
   if (raw_len < 0) raw_len = 0;
   WFE_STAMP(0);
   Chain c;
   int len = raw_len;
   if (AUG) {
-    c = make_chain(a, b, w, raw_len);
+    c = make_chain(a, b, src, raw_len);
     len = chain_len(c, c.n_ops);
   }
   if (len > n) len = n;                         // truncation=True (HF:300-307)
@@ -492,12 +519,40 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
 
   // ---- stage the padded-signal span [160 t0, 160 t0 + 10480) into LDS
   {
-    const bool interior = !AUG && i_first >= 0 && i_first + kBlockSamples <= len &&
-                          ((reinterpret_cast<uintptr_t>(w + i_first) & 15u) == 0);
+    const bool inside = !AUG && i_first >= 0 && i_first + kBlockSamples <= len;
+    const bool interior = inside && w && ((reinterpret_cast<uintptr_t>(w + i_first) & 15u) == 0);
+    const bool interior16 = inside && src.pcm && src.ch == 1 &&
+                            ((reinterpret_cast<uintptr_t>(src.pcm + i_first) & 15u) == 0);
     if (AUG) {
       stage_augmented<kAuxFloats>(c, lds, lds + kLdsWaveFloats, p0, n, len, tid);
-    } else
-    if (interior) {
+    } else if (interior16) {
+      // 16-bit PCM: 8 samples per 16-byte load, converted on the way into LDS
+      using i32x4 = __attribute__((ext_vector_type(4))) int;
+      const i32x4* __restrict__ src8 = reinterpret_cast<const i32x4*>(src.pcm + i_first);
+      constexpr int kVec = kBlockSamples / 8;               // 1310
+      constexpr int kIters = (kVec + 255) / 256;
+      i32x4 buf[kIters];
+#pragma unroll
+      for (int it = 0; it < kIters; ++it) {
+        const int v8 = tid + 256 * it;
+        if (v8 < kVec) buf[it] = src8[v8];
+      }
+      constexpr float kScale = 1.0f / 32768.0f;
+#pragma unroll
+      for (int it = 0; it < kIters; ++it) {
+        const int v8 = tid + 256 * it;
+        if (v8 < kVec) {
+          const int q = 8 * v8;                 // 8 | 160, so the eight share q / 160
+          const int base = q + q / kHop;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int pair = buf[it][j];
+            lds[base + 2 * j + 0] = (float)(short)(pair & 0xffff) * kScale;
+            lds[base + 2 * j + 1] = (float)(pair >> 16) * kScale;
+          }
+        }
+      }
+    } else if (interior) {
       // every load in flight before the first LDS write: one HBM round trip per tile
       const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(w + i_first);
       constexpr int kIters = (kBlockSamples / 4 + 255) / 256;
@@ -530,7 +585,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
           if (i < 0) i = -i;                    // torch.stft center=True, pad_mode="reflect"
           if (i >= n) i = 2 * (n - 1) - i;
           float v = 0.f;                        // right zero padding (padding_value 0.0)
-          if (q < kBlockSamples && i >= 0 && i < len) v = w[i];
+          if (q < kBlockSamples && i >= 0 && i < len) v = src.at(i);
           vals[u] = v;
         }
 #pragma unroll
@@ -912,10 +967,10 @@ __device__ inline int first_resolvable(const Chain& c) {
 __global__ __launch_bounds__(256) void resolve_partial_kernel(const FrontArgs a, double* __restrict__ partials) {
   __shared__ double sh[4];
   const int b = blockIdx.y, part = blockIdx.x;
-  const float* w = a.wav + (a.offsets ? a.offsets[b] : (long long)b * a.row_stride);
+  const Source src = make_source(a, b);
   int raw_len = a.lengths[b];
   if (raw_len < 0) raw_len = 0;
-  const Chain c = make_chain(a, b, w, raw_len);
+  const Chain c = make_chain(a, b, src, raw_len);
   const int k0 = first_resolvable(c);
   if (k0 < 0) return;
   int L = chain_len(c, k0);
@@ -932,7 +987,7 @@ __global__ __launch_bounds__(256) void resolve_partial_kernel(const FrontArgs a,
 #pragma unroll
       for (int u = 0; u < U; ++u) cur[u] = (i0 + 256 * u < hi) ? i0 + 256 * u + S : kDeadIndex;
 #pragma unroll
-      for (int u = 0; u < U; ++u) v[u] = (cur[u] >= 0 && cur[u] < c.len0) ? w[cur[u]] : 0.f;
+      for (int u = 0; u < U; ++u) v[u] = (cur[u] >= 0 && cur[u] < c.len0) ? src.at(cur[u]) : 0.f;
       seg_apply<U>(c, 0, k0, c.len0, cur, v);
 #pragma unroll
       for (int u = 0; u < U; ++u)
@@ -965,10 +1020,10 @@ __global__ __launch_bounds__(256) void resolve_partial_kernel(const FrontArgs a,
 __global__ __launch_bounds__(1024) void resolve_kernel(const FrontArgs a, const double* __restrict__ partials) {
   __shared__ double sh[16];
   const int b = blockIdx.x;
-  const float* w = a.wav + (a.offsets ? a.offsets[b] : (long long)b * a.row_stride);
+  const Source src = make_source(a, b);
   int raw_len = a.lengths[b];
   if (raw_len < 0) raw_len = 0;
-  const Chain c = make_chain(a, b, w, raw_len);
+  const Chain c = make_chain(a, b, src, raw_len);
   Resolved* res = a.resolved + a.op_begin[b];
   bool first = true;
   for (int k = 0; k < c.n_ops; ++k) {
@@ -1026,10 +1081,10 @@ __global__ __launch_bounds__(256) void waveform_kernel(const FrontArgs a, float*
   constexpr int kSpan = kBlockFrames * kHop;            // output samples per workgroup (10240)
   __shared__ __attribute__((aligned(16))) float lds[kLdsWaveFloats + kAux];
   const int b = blockIdx.y;
-  const float* w = a.wav + (a.offsets ? a.offsets[b] : (long long)b * a.row_stride);
+  const Source src = make_source(a, b);
   int raw_len = a.lengths[b];
   if (raw_len < 0) raw_len = 0;
-  const Chain c = make_chain(a, b, w, raw_len);
+  const Chain c = make_chain(a, b, src, raw_len);
   const int L = chain_len(c, c.n_ops);
   const int keep = L < a.n_samples ? L : a.n_samples;
   if (blockIdx.x == 0 && threadIdx.x == 0 && out_len) out_len[b] = L;

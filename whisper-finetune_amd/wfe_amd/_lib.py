@@ -41,6 +41,8 @@ SYMBOLS = {
     "wfe_power_spectrum": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
     "wfe_augment_logmel": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int64,
                                      _P, _P, C.c_int32, _P, _P]),
+    "wfe_logmel_pcm16": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int64,
+                                   _P, _P, C.c_int32, _P, _P]),
     "wfe_augment_waveform": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int64,
                                        _P, _P, C.c_int32, _P, _P, _P]),
     "wfe_kernel_timing": (C.c_int, [_P, C.c_int32]),

@@ -73,6 +73,107 @@ def read_audio(path: str, start: Optional[float] = None, end: Optional[float] = 
     return (pcm.reshape(-1, ch) if ch > 1 else pcm), sr
 
 
+_WAV_INFO: dict = {}     # path -> (sr, channels, data offset, frames) of a 16-bit PCM RIFF file, or None
+
+
+def _wav_info(path: str):
+    """Header of a 16-bit PCM RIFF/WAVE file (format tag 1, or 0xFFFE with the PCM
+    sub-format): (sample rate, channels, byte offset of the data chunk, frames).
+    None for anything else -- the caller then takes the float32 decode."""
+    if path in _WAV_INFO:
+        return _WAV_INFO[path]
+    info = None
+    try:
+        with open(path, "rb") as f:
+            head = f.read(12)
+            if len(head) == 12 and head[:4] == b"RIFF" and head[8:12] == b"WAVE":
+                fmt, pos = None, 12
+                while True:
+                    ck = f.read(8)
+                    if len(ck) < 8:
+                        break
+                    size = int.from_bytes(ck[4:8], "little")
+                    if ck[:4] == b"fmt ":
+                        body = f.read(size)
+                        tag = int.from_bytes(body[0:2], "little")
+                        ch = int.from_bytes(body[2:4], "little")
+                        sr = int.from_bytes(body[4:8], "little")
+                        bits = int.from_bytes(body[14:16], "little")
+                        if tag == 0xFFFE and size >= 26:
+                            tag = int.from_bytes(body[24:26], "little")
+                        fmt = (tag, ch, sr, bits)
+                        if size & 1:
+                            f.seek(1, 1)
+                    elif ck[:4] == b"data":
+                        if fmt and fmt[0] == 1 and fmt[3] == 16 and 1 <= fmt[1] <= 256:
+                            off = f.tell()
+                            avail = os.path.getsize(path) - off
+                            size = min(size, avail) if size not in (0, 0xFFFFFFFF) else avail
+                            info = (fmt[2], fmt[1], off, size // (2 * fmt[1]))
+                        break
+                    else:
+                        f.seek(size + (size & 1), 1)
+    except OSError:
+        info = None
+    _WAV_INFO[path] = info
+    return info
+
+
+class PcmRef:
+    """A span of 16-bit PCM frames inside a WAV file, not read yet: the collator's
+    packer reads it straight into its pinned staging buffer (``read_into``, one
+    ``pread``, GIL released), so the samples are touched once on the host.  Behaves
+    as a read-only int16 array of shape (frames, channels) where one is needed."""
+
+    dtype = np.dtype(np.int16)
+    ndim = 2
+
+    def __init__(self, path: str, byte_offset: int, frames: int, channels: int):
+        self.path, self.byte_offset, self.shape = path, int(byte_offset), (int(frames), int(channels))
+
+    def __len__(self):
+        return self.shape[0]
+
+    def read_into(self, dst: np.ndarray) -> None:
+        """dst: contiguous int16 array of frames * channels elements."""
+        want = self.shape[0] * self.shape[1] * 2
+        if want == 0:
+            return
+        view = memoryview(dst).cast("B")
+        fd = os.open(self.path, os.O_RDONLY)
+        try:
+            got = 0
+            while got < want:
+                n = os.preadv(fd, [view[got:want]], self.byte_offset + got)
+                if n <= 0:
+                    raise OSError(f"{self.path}: short read ({got} of {want} bytes)")
+                got += n
+        finally:
+            os.close(fd)
+
+    def __array__(self, dtype=None, copy=None):
+        out = np.empty(self.shape, dtype=np.int16)
+        self.read_into(out.reshape(-1))
+        return out if dtype is None else out.astype(dtype)
+
+    def __getitem__(self, key):
+        return np.asarray(self)[key]
+
+
+def read_pcm16(path: str, start: Optional[float] = None, end: Optional[float] = None):
+    """The samples of a 16-bit PCM WAV file as they lie in the file: a ``PcmRef``
+    (int16 (frames, channels), read lazily, no host conversion pass) and the sample
+    rate, or None when the file is anything else.  soundfile.read(dtype='float32')
+    of such a file is exactly these values / 32768 -- the division happens on the
+    GPU (include/wfe.h wfe_logmel_pcm16).  Slicing as reader.py:222-243."""
+    info = _wav_info(path)
+    if info is None:
+        return None
+    sr, ch, off, total = info
+    s, e = (0, total) if start is None else _slice_frames(start, end, total, sr)
+    return PcmRef(path, off + 2 * ch * s, max(e - s, 0), ch), sr
+
+
 def _slice_frames(start, end, total, sr):
     duration = round(float(total) / sr, 3)
     start, end = round(start, 3), round(end, 3)
@@ -143,6 +244,9 @@ class CustomDataset(torch.utils.data.Dataset):
         self._decoded: dict = {}
         self._pool = None
         self._pool_size = int(os.environ.get("WFE_DECODE_THREADS", "8"))
+        # 16-bit PCM files go to the GPU as int16 (converted and mixed down there); WFE_PCM16=0 restores
+        # the float32 host decode for every file
+        self._pcm16 = os.environ.get("WFE_PCM16", "1") == "1"
         self.augment_configs = None
         self.spec_aug = None
         self.noise_files: Optional[List[str]] = None
@@ -225,21 +329,33 @@ class CustomDataset(torch.utils.data.Dataset):
         language = rec["language"] if "language" in rec else None
         if idx in self._decoded:
             sample, sr = self._decoded.pop(idx)
-        elif "start_time" not in rec["audio"]:
-            sample, sr = read_audio(path)
         else:
-            sample, sr = read_audio(path, rec["audio"]["start_time"], rec["audio"]["end_time"])
-        sample = sample.T
-        if self.mono and sample.ndim > 1:
-            sample = np.mean(sample, axis=0)                  # librosa.to_mono
-        sample = np.ascontiguousarray(sample, dtype=np.float32)
+            sample, sr = self._decode(rec["audio"])
+        if isinstance(sample, PcmRef):
+            n_frames = sample.shape[0]                        # (frames, channels) int16, mixed down on the GPU
+        else:
+            sample = sample.T
+            if self.mono and sample.ndim > 1:
+                sample = np.mean(sample, axis=0)              # librosa.to_mono
+            sample = np.ascontiguousarray(sample, dtype=np.float32)
+            n_frames = len(sample)
         ops = []
         if self.augment_configs:
-            ops, _ = self.planner.draw(len(sample), sr)
+            ops, _ = self.planner.draw(n_frames, sr)
         if self.sample_rate != sr:
             raise NotImplementedError(f"{path} is {sr} Hz: resampling to {self.sample_rate} Hz is not on the GPU "
                                       "path yet (SURVEY 8f N2)")
         return rec["id"] if "id" in rec else path, sample, sr, transcript, language, ops
+
+    def _decode(self, audio: dict):
+        """reader.py:142-148.  16-bit PCM stays int16 (see read_pcm16) when the
+        utterance ends up mono anyway; everything else is decoded to float32."""
+        start, end = (audio["start_time"], audio["end_time"]) if "start_time" in audio else (None, None)
+        if self._pcm16:
+            got = read_pcm16(audio["path"], start, end)
+            if got is not None and (got[0].shape[1] == 1 or self.mono):
+                return got
+        return read_audio(audio["path"], start, end)
 
     def _load_timestamps_transcript(self, transcript: List[dict]):
         """reader.py:164-179: <|t|> tokens are timestamp_begin + centiseconds // 2, odd
@@ -290,12 +406,21 @@ class CustomDataset(torch.utils.data.Dataset):
             def decode(idx):
                 try:
                     rec = self._binary.get(self.data_list[idx]) if self._binary else self.data_list[idx]
-                    a = rec["audio"]
-                    return read_audio(a["path"], a.get("start_time"), a.get("end_time")) if "start_time" in a \
-                        else read_audio(a["path"])
+                    return self._decode(rec["audio"])
                 except Exception as e:  # noqa: BLE001 -- surfaced again (and reported) by __getitem__
                     return e
-            for idx, res in zip(indices, self._pool.map(decode, indices)):
+            # 16-bit PCM files are not read here at all (PcmRef: the packer reads them) -- only
+            # files that need a real decode go through the pool
+            def needs_decode(idx):
+                if not self._pcm16:
+                    return True
+                try:
+                    rec = self._binary.get(self.data_list[idx]) if self._binary else self.data_list[idx]
+                    return _wav_info(rec["audio"]["path"]) is None
+                except Exception:  # noqa: BLE001
+                    return False
+            todo = [i for i in indices if needs_decode(i)]
+            for idx, res in zip(todo, self._pool.map(decode, todo) if todo else ()):
                 if not isinstance(res, Exception):
                     self._decoded[idx] = res
         try:
@@ -351,6 +476,7 @@ class DataCollatorSpeechSeq2SeqWithPadding:
             else bool(device_output)
         self._noise_src = noise_clips
         self._noise_bank = None
+        self._packer = None
 
     def set_noise_clips(self, clips):
         """The decoded noise clips of ``CustomDataset.noise_clips`` (uploaded once)."""
@@ -368,17 +494,20 @@ class DataCollatorSpeechSeq2SeqWithPadding:
                                    "worker cannot use the GPU -- launch with --num_workers 0 (host decode is "
                                    "parallelised inside CustomDataset.__getitems__)")
             from .feature_extractor import front_end
-            from .frontend import NoiseBank, pack_ragged
+            from .frontend import NoiseBank, RaggedPacker
             fe = front_end(n_mel, self.device)
-            flat, off, lens = pack_ragged([items[i]["waveform"] for i in gpu_items], fe.device)
+            if self._packer is None or self._packer.device != fe.device:
+                self._packer = RaggedPacker(fe.device, int(os.environ.get("WFE_DECODE_THREADS", "8")))
+            flat, off, lens, ch = self._packer.pack([items[i]["waveform"] for i in gpu_items])
             plans = [items[i].get("aug_ops") or [] for i in gpu_items]
             if any(plans):
                 src = self._noise_src if self._noise_src is not None else _NOISE_CLIPS.get(id(self.processor))
                 if self._noise_bank is None and src:
                     self._noise_bank = NoiseBank(src, fe.device)
-                out = fe.augment_logmel(flat, lens, plans, self._noise_bank, n_samples=n_samples, offsets=off)
+                out = fe.augment_logmel(flat, lens, plans, self._noise_bank, n_samples=n_samples, offsets=off,
+                                        channels=ch)
             else:
-                out = fe.logmel(flat, lens, n_samples=n_samples, offsets=off)
+                out = fe.logmel(flat, lens, n_samples=n_samples, offsets=off, channels=ch)
             for j, i in enumerate(gpu_items):             # reader.py:355-389 on the (1, M, T) layout
                 sa = items[i].get("specaug")
                 if sa:

@@ -78,9 +78,10 @@ class HipFrontEnd:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _check_inputs(self, wav, lengths, offsets, batch):
-        for name, t, dt in (("wav", wav, torch.float32), ("lengths", lengths, torch.int32)):
-            if t.device != self.device or t.dtype != dt or not t.is_contiguous():
-                raise ValueError(f"{name} must be a contiguous {dt} tensor on {self.device}")
+        if wav.dtype not in (torch.float32, torch.int16) or wav.device != self.device or not wav.is_contiguous():
+            raise ValueError(f"wav must be a contiguous float32 (or int16 PCM) tensor on {self.device}")
+        if lengths.device != self.device or lengths.dtype != torch.int32 or not lengths.is_contiguous():
+            raise ValueError(f"lengths must be a contiguous int32 tensor on {self.device}")
         if lengths.numel() != batch:
             raise ValueError("lengths must have one entry per utterance")
         if offsets is not None and (offsets.device != self.device or offsets.dtype != torch.int64
@@ -105,9 +106,12 @@ class HipFrontEnd:
 
     # ---------------------------------------------------------------- hot path
     def logmel(self, wav: torch.Tensor, lengths: torch.Tensor, n_samples: int = N_SAMPLES,
-               offsets: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+               offsets: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+               channels: int = 1) -> torch.Tensor:
         """(B, n_mel, n_samples // 160) float32 on the device.  ``wav`` is (B, stride)
-        or, with ``offsets``, a flat buffer of ragged utterances."""
+        or, with ``offsets``, a flat buffer of ragged utterances; float32 samples, or
+        int16 PCM with ``channels`` interleaved channels (lengths in frames, offsets and
+        stride in int16 elements), converted and mixed down on the device."""
         batch, stride = self._geometry(wav, lengths, offsets)
         self._check_inputs(wav, lengths, offsets, batch)
         shape = (batch, self.n_mel, n_samples // HOP)
@@ -116,6 +120,11 @@ class HipFrontEnd:
         elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() \
                 or out.device != self.device:
             raise ValueError(f"out must be a contiguous float32 {shape} tensor on {self.device}")
+        if wav.dtype == torch.int16:
+            _lib.check(_lib.lib().wfe_logmel_pcm16(
+                self._h, _ptr(wav), _ptr(offsets), _ptr(lengths), stride, int(channels), batch, int(n_samples),
+                None, None, 0, None, None, 0, _ptr(out), self._stream()), self._h)
+            return out
         _lib.check(_lib.lib().wfe_logmel(self._h, _ptr(wav), _ptr(offsets), _ptr(lengths), stride, batch,
                                          int(n_samples), _ptr(out), self._stream()), self._h)
         return out
@@ -157,7 +166,7 @@ class HipFrontEnd:
         return self.pack_plans(plans)
 
     def augment_logmel(self, wav, lengths, plans, noise: Optional[NoiseBank] = None, n_samples: int = N_SAMPLES,
-                       offsets=None, out=None) -> torch.Tensor:
+                       offsets=None, out=None, channels: int = 1) -> torch.Tensor:
         batch, stride = self._geometry(wav, lengths, offsets)
         self._check_inputs(wav, lengths, offsets, batch)
         ops, begin, total = self._pack_ops(plans)
@@ -166,10 +175,14 @@ class HipFrontEnd:
         shape = (batch, self.n_mel, n_samples // HOP)
         if out is None:
             out = torch.empty(shape, dtype=torch.float32, device=self.device)
-        _lib.check(_lib.lib().wfe_augment_logmel(
-            self._h, _ptr(wav), _ptr(offsets), _ptr(lengths), stride, batch, int(n_samples), _ptr(ops), _ptr(begin),
-            total, _ptr(noise.data) if noise else None, _ptr(noise.offsets) if noise else None,
-            noise.n if noise else 0, _ptr(out), self._stream()), self._h)
+        tail = (_ptr(ops), _ptr(begin), total, _ptr(noise.data) if noise else None,
+                _ptr(noise.offsets) if noise else None, noise.n if noise else 0, _ptr(out), self._stream())
+        if wav.dtype == torch.int16:
+            _lib.check(_lib.lib().wfe_logmel_pcm16(self._h, _ptr(wav), _ptr(offsets), _ptr(lengths), stride,
+                                                   int(channels), batch, int(n_samples), *tail), self._h)
+        else:
+            _lib.check(_lib.lib().wfe_augment_logmel(self._h, _ptr(wav), _ptr(offsets), _ptr(lengths), stride, batch,
+                                                     int(n_samples), *tail), self._h)
         return out
 
     def augment_waveform(self, wav, lengths, plans, noise: Optional[NoiseBank] = None, n_samples: int = N_SAMPLES,
@@ -202,3 +215,88 @@ def pack_ragged(waves: Sequence[np.ndarray], device: torch.device, pinned: bool 
         fnp[o:o + len(w)] = np.asarray(w, dtype=np.float32).reshape(-1)
     return (flat.to(device, non_blocking=pinned), torch.from_numpy(off).to(device),
             torch.from_numpy(lens.astype(np.int32)).to(device))
+
+
+class RaggedPacker:
+    """Host list of utterances -> one pinned staging buffer -> ONE host-to-device
+    copy per batch.  Utterances are float32 (N,) or 16-bit PCM int16 (frames,
+    channels) as ``read_pcm16`` maps them; a batch that is all int16 with one channel
+    count travels as int16 (half the bytes, no host conversion) and is converted on
+    the GPU, any other batch as float32 mono.  The int64 offsets and int32 lengths
+    ride in the same buffer.  Two pinned buffers alternate so that batch i+1 can be
+    packed while the copy of batch i is still in flight; each is reused only after
+    its copy's event has completed."""
+
+    def __init__(self, device: torch.device, threads: int = 8):
+        self.device = device
+        self._bufs = [None, None]
+        self._events = [None, None]
+        self._turn = 0
+        self._threads = max(1, int(threads))
+        self._pool = None
+
+    @staticmethod
+    def _as_float_mono(w: np.ndarray) -> np.ndarray:
+        if w.dtype == np.int16:             # soundfile float32 decode + librosa.to_mono, on the host
+            f = np.asarray(w).astype(np.float32) / np.float32(32768.0)
+            return f.reshape(-1) if f.ndim == 1 or f.shape[1] == 1 else np.mean(f.T, axis=0)
+        return np.asarray(w, dtype=np.float32).reshape(-1)
+
+    def pack(self, waves: Sequence[np.ndarray]):
+        """-> (flat device tensor, int64 offsets, int32 lengths, channels); offsets
+        count elements of ``flat``, lengths count frames."""
+        n = len(waves)
+        pcm = n > 0 and all(getattr(w, "dtype", None) == np.int16 for w in waves)
+        ch = 1
+        if pcm:
+            chans = {1 if w.ndim == 1 else w.shape[1] for w in waves}
+            pcm = len(chans) == 1
+            ch = chans.pop() if pcm else 1
+        if not pcm:
+            waves = [self._as_float_mono(w) for w in waves]
+        item = 2 if pcm else 4
+        dtype = np.int16 if pcm else np.float32
+        frames = np.array([w.shape[0] for w in waves], dtype=np.int64)
+        elems = frames * ch
+        per16 = 16 // item                                       # utterances start on 16-byte boundaries
+        padded = (elems + per16 - 1) // per16 * per16
+        off = np.zeros(n, dtype=np.int64)
+        if n > 1:
+            off[1:] = np.cumsum(padded)[:-1]
+        total = int(padded.sum()) if n else 0
+        head = (12 * n + 15) // 16 * 16                          # offsets (8n) + lengths (4n), padded
+        nbytes = head + max(total, per16) * item
+        k = self._turn
+        self._turn ^= 1
+        if self._events[k] is not None:
+            self._events[k].synchronize()
+        if self._bufs[k] is None or self._bufs[k].numel() < nbytes:
+            self._bufs[k] = torch.empty(int(nbytes * 1.25) + 4096, dtype=torch.uint8, pin_memory=True)
+        host = self._bufs[k].numpy()
+        host[:8 * n].view(np.int64)[:] = off
+        host[8 * n:12 * n].view(np.int32)[:] = frames.astype(np.int32)
+        body = host[head:head + total * item].view(dtype)
+
+        def put(i):
+            w = waves[i]
+            if hasattr(w, "read_into"):                          # data.PcmRef: file -> pinned buffer, one pread
+                w.read_into(body[off[i]:off[i] + elems[i]])
+            else:
+                body[off[i]:off[i] + elems[i]] = w.reshape(-1)
+            body[off[i] + elems[i]:off[i] + padded[i]] = 0
+
+        if n >= 4 and total * item >= (8 << 20) and self._threads > 1:
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(self._threads)
+            list(self._pool.map(put, range(n)))
+        else:
+            for i in range(n):
+                put(i)
+        dev = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        dev.copy_(self._bufs[k][:nbytes], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._events[k] = ev
+        flat = dev[head:head + max(total, per16) * item].view(torch.int16 if pcm else torch.float32)
+        return flat, dev[:8 * n].view(torch.int64), dev[8 * n:12 * n].view(torch.int32), ch
