@@ -42,7 +42,7 @@ namespace wfe {
     if (a.stamps && lane == 0) {                                                       \
       unsigned long long t_;                                                           \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
-      a.stamps[((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8 + (i)] = t_; \
+      a.stamps[((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + blockIdx.x) * 4 + wave) * 8 + (i)] = t_; \
     }                                                                                  \
   } while (0)
 #else
@@ -76,6 +76,26 @@ __device__ __forceinline__ unsigned enc_max(float v) {
 }
 __device__ __forceinline__ float dec_max(unsigned k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// max / min over the 64 lanes without LDS traffic (ds_bpermute queues behind the
+// partner workgroup's k-loop reads): four DPP row rotations leave every lane with
+// its row's value, four v_readlane combine the rows.  Result uniform.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <bool MAX>
+__device__ __forceinline__ float wave_reduce(float v) {
+  auto op = [](float x, float y) { return MAX ? fmaxf(x, y) : fminf(x, y); };
+  v = op(v, dpp_mov<0x128>(v));      // row_ror:8
+  v = op(v, dpp_mov<0x124>(v));      // row_ror:4
+  v = op(v, dpp_mov<0x122>(v));      // row_ror:2
+  v = op(v, dpp_mov<0x121>(v));      // row_ror:1
+  const int iv = __float_as_int(v);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(iv, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(iv, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(iv, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(iv, 48));
+  return op(op(r0, r1), op(r2, r3));
 }
 
 // ------------------------------------------------- augmentation chain (AUG only)
@@ -433,6 +453,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   const int t0 = blockIdx.x * kBlockFrames;
   const int n = a.n_samples;
   const int T = a.n_frames;
+  const int nblk = (T + kBlockFrames - 1) / kBlockFrames;   // == gridDim.x, without the late kernarg load
   const Source src = make_source(a, b);
   const float* __restrict__ w = src.w;
   int raw_len = a.lengths[b];
@@ -469,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
         // clamp, so kernel 2 (which knows the utterance maximum) writes its final value
         // once.  -inf marks the tile as silent; real minima are >= -10.
         if (tid == 0) atomicMax(a.clip_max + b, enc_max(-10.0f));
-        if (tid < 4) a.block_min[((long long)b * gridDim.x + blockIdx.x) * 4 + tid] = -INFINITY;
+        if (tid < 4) a.block_min[((long long)b * nblk + blockIdx.x) * 4 + tid] = -INFINITY;
       }
       return;
     }
@@ -492,11 +513,11 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
     __syncthreads();
     const unsigned ticket = __float_as_uint(lds[0]);
     __syncthreads();
-#ifdef WFE_STAMPS
+#if defined(WFE_STAMPS) && WFE_STAMPS == 1
     if (a.stamps && lane == 0) {
       const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
       const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
-      unsigned long long* st = a.stamps + ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8;
+      unsigned long long* st = a.stamps + ((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + blockIdx.x) * 4 + wave) * 8;
       st[6] = ((unsigned long long)xcc << 32) | hw;
       st[7] = ticket;
     }
@@ -730,9 +751,9 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   }
 
   WFE_STAMP(3);
-#ifdef WFE_STAMPS
+#if defined(WFE_STAMPS) && WFE_STAMPS == 1
   if (a.stamps && lane == 0)
-    a.stamps[((long long)(blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 8 + 7] = barrier_cycles;
+    a.stamps[((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + blockIdx.x) * 4 + wave) * 8 + 7] = barrier_cycles;
 #endif
   // Mel weight fragments of every live (bin tile, mel tile) block: all requested
   // here, ahead of the butterflies, so that the mel phase pays one L2 round trip
@@ -837,24 +858,38 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
         wmin = fminf(wmin, v);
       }
     }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    wmax = fmaxf(wmax, __shfl_xor(wmax, d, 64));
-    wmin = fminf(wmin, __shfl_xor(wmin, d, 64));
-  }
+  wmax = wave_reduce<true>(wmax);
+  wmin = wave_reduce<false>(wmin);
+#if defined(WFE_STAMPS) && WFE_STAMPS == 3
+  WFE_STAMP(6);
+#endif
   if (lane == 0) {
     if (wmax > -INFINITY) atomicMax(a.clip_max + b, enc_max(wmax));
-    a.block_min[((long long)b * gridDim.x + blockIdx.x) * 4 + wave] = wmin;
+    a.block_min[((long long)b * nblk + blockIdx.x) * 4 + wave] = wmin;
   }
+#if defined(WFE_STAMPS) && WFE_STAMPS == 2
+  WFE_STAMP(6);
+#endif
+#if defined(WFE_STAMPS) && WFE_STAMPS == 3
+  WFE_STAMP(7);
+#endif
   __syncthreads();
+#if defined(WFE_STAMPS) && WFE_STAMPS == 2
+  WFE_STAMP(7);
+#endif
   float* __restrict__ lo = a.out + (long long)b * a.n_mel * T + t0;
   const int frames_here = (T - t0 < kBlockFrames) ? (T - t0) : kBlockFrames;
   if ((T & 3) == 0 && (reinterpret_cast<uintptr_t>(lo) & 15u) == 0) {
-    for (int idx = tid; idx < a.n_mel * (kBlockFrames / 4); idx += 256) {
-      const int mel = idx >> 4, c4 = idx & 15;
-      if (4 * c4 < frames_here)                         // T % 4 == 0: a float4 is all-valid or all-out
-        *reinterpret_cast<f32x4*>(lo + (long long)mel * T + 4 * c4) =
-            *reinterpret_cast<const f32x4*>(tile + mel * kTileStride + 4 * c4);
+    constexpr int kIt = 16 * NMT / 16;                  // (16 NMT rows x 16 float4) / 256 threads
+    f32x4 row[kIt];
+#pragma unroll
+    for (int it = 0; it < kIt; ++it)
+      row[it] = *reinterpret_cast<const f32x4*>(tile + (it * 16 + (tid >> 4)) * kTileStride + 4 * (tid & 15));
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+      const int mel = it * 16 + (tid >> 4), c4 = tid & 15;
+      if (mel < a.n_mel && 4 * c4 < frames_here)        // T % 4 == 0: a float4 is all-valid or all-out
+        *reinterpret_cast<f32x4*>(lo + (long long)mel * T + 4 * c4) = row[it];
     }
   } else {
     for (int idx = tid; idx < a.n_mel * kBlockFrames; idx += 256) {

@@ -10,7 +10,8 @@ import os
 import torch  # noqa: F401  -- loads torch's libamdhip64.so.7 first so that ours binds to the same runtime
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwfe_hip.so")
+# WFE_LIB_PATH: a diagnostic build of the same library (stamps, experiments); never a different implementation
+LIB_PATH = os.environ.get("WFE_LIB_PATH") or os.path.join(_HERE, "libwfe_hip.so")
 
 
 class WfeError(RuntimeError):
