@@ -136,6 +136,24 @@ int wfe_logmel_pcm16(wfe_handle h, const int16_t* pcm, const int64_t* offsets, c
                      const float* noise, const int64_t* noise_offsets, int32_t n_noise,
                      float* out, void* stream);
 
+/* CustomDataset.resample (utils/reader.py:316-319 = librosa.resample, used for the
+ * resample augmentation :263-266 and the return to 16 kHz :157-158) for a batch:
+ * out[b, n] = sum_k in_b[k] h(k - n in_rate/out_rate), zero-phase, zeros outside the
+ * utterance.  PARITY UNPINNED: the reference's filter is soxr 'soxr_hq' (third-party,
+ * not available); h is resampy's 'kaiser_best' design evaluated exactly
+ * (whisper-finetune_amd/csrc/wfe_tables.cpp, oracle/resample.py).
+ *   in           device float32 (pcm_channels == 0) or interleaved int16 PCM with
+ *                pcm_channels channels (converted and mixed down as wfe_logmel_pcm16)
+ *   lengths      device int32[batch], input frames
+ *   out          device float32 (batch, out_stride); row b is zero behind out_lengths[b]
+ *   out_lengths  device int32[batch], GIVEN by the caller: librosa's
+ *                int(ceil(n * (float(out_rate) / in_rate)))
+ * Ratios whose reduced numerator out_rate/gcd exceeds 4096, or that decimate by
+ * more than ~100, are rejected with WFE_ERR_ARG. */
+int wfe_resample(wfe_handle h, const void* in, int32_t pcm_channels, const int64_t* offsets,
+                 const int32_t* lengths, int64_t row_stride, int32_t batch, int32_t in_rate, int32_t out_rate,
+                 float* out, int64_t out_stride, const int32_t* out_lengths, void* stream);
+
 /* The augmented, padded waveform itself, (batch, n_samples) float32: what
  * CustomDataset._get_list_data returns (utils/reader.py:134-162) after pad/trim.
  * Used by the parity tests of the augmentation stages. */
@@ -168,6 +186,10 @@ int wfe_build_dft_table(float* host_out);
 int wfe_build_mel_table(int32_t n_mel, float* host_out, uint32_t* mask14);
 int wfe_build_mel_filters(int32_t n_mel, double* host_out /* (201, n_mel) */);
 /* n for (parity class, k-step, k-lane) of the folded DFT. */
+/* resampling filter: out_rate/in_rate = L/M reduced, taps per phase, index of the
+ * centre tap; table [taps][L] float32 */
+int wfe_resample_geometry(int32_t in_rate, int32_t out_rate, int32_t* L, int32_t* M, int32_t* taps, int32_t* k0);
+int wfe_build_resample_table(int32_t in_rate, int32_t out_rate, float* out);
 int32_t wfe_dft_n_of(int32_t parity_class, int32_t step, int32_t kk);
 
 const char* wfe_version(void);

@@ -1,0 +1,97 @@
+"""GPU resampler (include/wfe.h wfe_resample) against the float64 oracle
+(oracle/resample.py).  PARITY UNPINNED with respect to the reference's soxr filter
+(see the oracle's header); what is pinned here is the kernel against the restated
+filter: |err| <= 2e-6 * max|x| (float32 table and accumulation over <= ~800 taps),
+librosa's length rule, zero-phase alignment, and -- independently of our own filter
+-- agreement with scipy.signal.resample_poly's default design to 1e-3 in the interior
+and the behaviour on pure tones (pass band exact, stop band gone)."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oracle import resample as rs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fe():
+    from wfe_amd.frontend import HipFrontEnd
+    return HipFrontEnd(n_mel=80, device=0)
+
+
+def _signal(seed, n, sr):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n) / sr
+    return (0.3 * np.sin(2 * np.pi * 440 * t) + 0.05 * rng.standard_normal(n)).astype(np.float32)
+
+
+@pytest.mark.parametrize("orig,target", [(44100, 16000), (8000, 16000), (48000, 16000), (22050, 16000),
+                                         (32000, 16000), (16000, 8000), (16000, 44100), (11025, 16000)])
+def test_resample_matches_oracle(fe, orig, target):
+    from wfe_amd.frontend import pack_ragged
+    waves = [_signal(i, n, orig) for i, n in enumerate((orig * 2 + 17, 5000, 1, 12345))]
+    flat, off, lens = pack_ragged(waves, fe.device)
+    out, out_len = fe.resample(flat, lens, orig, target, offsets=off)
+    torch.cuda.synchronize()
+    out, out_len = out.cpu().numpy(), out_len.cpu().numpy()
+    for i, w in enumerate(waves):
+        want = rs.resample(w, orig, target)
+        assert out_len[i] == len(want) == rs.output_length(len(w), orig, target)
+        err = np.abs(out[i, :len(want)] - want).max()
+        assert err <= 2e-6 * max(np.abs(w).max(), 1e-3), (i, err)
+        assert not out[i, len(want):].any()
+
+
+def test_resample_pcm16_stereo_and_dense_rows(fe):
+    rng = np.random.default_rng(3)
+    pcm = rng.integers(-20000, 20000, size=(3, 50000, 2), dtype=np.int16)
+    dense = torch.from_numpy(pcm.reshape(3, -1)).to(fe.device)
+    lens = torch.tensor([50000, 31000, 0], dtype=torch.int32, device=fe.device)
+    out, out_len = fe.resample(dense, lens, 44100, 16000, channels=2)
+    torch.cuda.synchronize()
+    for b, n in enumerate((50000, 31000, 0)):
+        mono = np.mean((pcm[b, :n].astype(np.float32) / np.float32(32768.0)).T, axis=0) if n else np.zeros(0, np.float32)
+        want = rs.resample(mono, 44100, 16000)
+        assert int(out_len[b]) == len(want)
+        if n:
+            assert np.abs(out[b, :len(want)].cpu().numpy() - want).max() <= 2e-6
+        assert not out[b, len(want):].any()
+
+
+def test_resample_quality_independent_checks(fe):
+    """Independent of our own filter restatement, 44.1 kHz -> 16 kHz: a 1 kHz tone and a
+    20-tone mixture below 6 kHz come out as the same tones sampled at the new rate (zero
+    phase, unit gain), a 12 kHz tone (above the new Nyquist) is removed, and the mixture
+    agrees with scipy.signal.resample_poly (a different, shorter filter design) to 2e-3."""
+    from scipy.signal import resample_poly
+    sr = 44100
+    t = np.arange(sr) / sr
+    tt = np.arange(16000) / 16000
+    rng = np.random.default_rng(11)
+    freqs, phases = rng.uniform(100, 6000, 20), rng.uniform(0, 2 * np.pi, 20)
+    mix = lambda tm: sum(0.04 * np.sin(2 * np.pi * f * tm + ph) for f, ph in zip(freqs, phases))     # noqa: E731
+    x = np.stack([np.sin(2 * np.pi * 1000 * t), np.sin(2 * np.pi * 12000 * t), mix(t)]).astype(np.float32)
+    lens = torch.full((3,), sr, dtype=torch.int32, device=fe.device)
+    out, out_len = fe.resample(torch.from_numpy(x).to(fe.device), lens, sr, 16000)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    inner = slice(1000, 15000)
+    assert out_len.cpu().tolist() == [16000] * 3
+    assert np.abs(out[0, :16000] - np.sin(2 * np.pi * 1000 * tt))[inner].max() <= 1e-5
+    assert np.abs(out[1, :16000])[inner].max() <= 1e-5
+    assert np.abs(out[2, :16000] - mix(tt))[inner].max() <= 1e-5
+    ref = resample_poly(x[2].astype(np.float64), 160, 441)
+    assert np.abs(out[2, :16000] - ref[:16000])[inner].max() <= 2e-3
+
+
+def test_resample_argument_errors(fe):
+    x = torch.zeros((1, 1000), device=fe.device)
+    lens = torch.tensor([1000], dtype=torch.int32, device=fe.device)
+    with pytest.raises(ValueError):
+        fe.resample(x, lens, 16001, 16000)          # 16000 filter phases
+    with pytest.raises(ValueError):
+        fe.resample(x, lens, 4000000, 16000)        # decimation by 250
+    with pytest.raises(ValueError):
+        fe.resample(x, lens, 0, 16000)

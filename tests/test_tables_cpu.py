@@ -114,3 +114,29 @@ def test_packed_tables_reproduce_oracle(n_mel):
     assert np.abs(got_p - want_p).max() <= 2e-6 * scale
     want_m = ol.mel_filter_bank(n_mel).T @ want_p
     assert np.abs(melp - want_m).max() <= 2e-6 * want_m.max()
+
+
+def test_resample_table_matches_oracle_filter():
+    """The float32 polyphase table the kernel reads ([taps][L]) against the float64
+    filter of oracle/resample.py, for down-, up- and awkward ratios; DC gain 1."""
+    import ctypes as C
+    from oracle import resample as rs
+    from wfe_amd import _lib
+    lib = _lib.lib()
+    for orig, target in ((44100, 16000), (8000, 16000), (48000, 16000), (22050, 16000), (16000, 44100), (32000, 16000)):
+        L, M, taps, k0 = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        assert lib.wfe_resample_geometry(orig, target, C.byref(L), C.byref(M), C.byref(taps), C.byref(k0)) == 0
+        from math import gcd
+        g = gcd(orig, target)
+        assert (L.value, M.value) == (target // g, orig // g)
+        scale = min(1.0, target / orig)
+        assert k0.value == int(np.floor(rs.ZEROS / scale)) and taps.value == 2 * k0.value + 2
+        tab = np.zeros((taps.value, L.value), dtype=np.float32)
+        assert lib.wfe_build_resample_table(orig, target, tab.ctypes.data) == 0
+        j = np.arange(taps.value)[:, None]
+        p = np.arange(L.value)[None, :]
+        want = rs.filter_value((j - k0.value) - p / L.value, scale)
+        assert np.abs(tab - want).max() <= 1e-7
+        assert np.abs(tab.astype(np.float64).sum(axis=0) - 1.0).max() <= 2e-5      # every phase: unit DC gain
+    bad = C.c_int32()
+    assert lib.wfe_resample_geometry(0, 16000, C.byref(bad), C.byref(bad), C.byref(bad), C.byref(bad)) != 0

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <new>
 #include <string>
 #include <vector>
@@ -34,6 +35,11 @@ struct wfe_context {
   std::vector<hipEvent_t> ev_pool;      // triples: before K1, after K1, after K2
   size_t ev_used = 0;
   double* d_partials = nullptr;             // resolve pass: per-part sums of the batch slice
+  struct RsTable {
+    float* d = nullptr;
+    int L = 0, M = 0, taps = 0, k0 = 0;
+  };
+  std::map<std::pair<int, int>, RsTable> rs_tables;   // (in_rate, out_rate) -> filter on the device
   float* d_block_min = nullptr;             // per-wave minima of kernel 1, grows on demand
   size_t block_min_cap = 0;
   unsigned long long* d_stamps = nullptr;   // diagnostic builds only (wfe_debug_stamps)
@@ -291,6 +297,8 @@ int wfe_destroy(wfe_handle h) {
   if (h->d_resolved) (void)hipFree(h->d_resolved);
   if (h->d_noise_meansq) (void)hipFree(h->d_noise_meansq);
   if (h->d_block_min) (void)hipFree(h->d_block_min);
+  for (auto& kv : h->rs_tables)
+    if (kv.second.d) (void)hipFree(kv.second.d);
   if (h->d_partials) (void)hipFree(h->d_partials);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   delete h;
@@ -400,6 +408,76 @@ int wfe_augment_waveform(wfe_handle h, const float* wav, const int64_t* offsets,
     HIP_TRY(h, wfe::launch_resolve(a, s.count, h->d_partials, stream));
     HIP_TRY(h, wfe::launch_waveform(a, s.count, out + (long long)s.begin * n_samples,
                                     out_lengths ? out_lengths + s.begin : nullptr, stream));
+  }
+  return WFE_OK;
+}
+
+int wfe_resample(wfe_handle h, const void* in, int32_t pcm_channels, const int64_t* offsets, const int32_t* lengths,
+                 int64_t row_stride, int32_t batch, int32_t in_rate, int32_t out_rate, float* out, int64_t out_stride,
+                 const int32_t* out_lengths, void* stream_) {
+  if (!h) return fail(nullptr, WFE_ERR_ARG, "null handle");
+  if (batch < 0) return fail(h, WFE_ERR_ARG, "batch %d < 0", batch);
+  if (pcm_channels < 0 || pcm_channels > 256) return fail(h, WFE_ERR_ARG, "pcm_channels %d outside 0..256", pcm_channels);
+  if (in_rate < 1 || out_rate < 1) return fail(h, WFE_ERR_ARG, "bad rates %d -> %d", in_rate, out_rate);
+  if (out_stride < 1 || out_stride >= (1LL << 30)) return fail(h, WFE_ERR_ARG, "bad out_stride");
+  if (offsets == nullptr && row_stride < 0) return fail(h, WFE_ERR_ARG, "negative row_stride");
+  if (batch == 0) return WFE_OK;
+  if (!in || !lengths || !out || !out_lengths) return fail(h, WFE_ERR_ARG, "null device pointer");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DeviceGuard guard(h->cfg.device);
+  if (!guard.ok) return fail(h, WFE_ERR_HIP, "hipSetDevice(%d) failed", h->cfg.device);
+  auto key = std::make_pair((int)in_rate, (int)out_rate);
+  auto it = h->rs_tables.find(key);
+  if (it == h->rs_tables.end()) {
+    wfe_context::RsTable t;
+    if (wfe_resample_geometry(in_rate, out_rate, &t.L, &t.M, &t.taps, &t.k0) != WFE_OK)
+      return fail(h, WFE_ERR_ARG, "unsupported resampling ratio %d -> %d", in_rate, out_rate);
+    if (t.L > wfe::kRsChunkFloats)
+      return fail(h, WFE_ERR_ARG, "resampling %d -> %d needs %d filter phases (> %d)", in_rate, out_rate, t.L,
+                  wfe::kRsChunkFloats);
+    if (t.taps + 2 + 256LL * t.M / t.L + 1 > wfe::kRsSpanFloats)
+      return fail(h, WFE_ERR_ARG, "resampling %d -> %d decimates too steeply (%d taps)", in_rate, out_rate, t.taps);
+    std::vector<float> host((size_t)t.taps * t.L);
+    wfe_build_resample_table(in_rate, out_rate, host.data());
+    HIP_TRY(h, hipMalloc(&t.d, host.size() * sizeof(float)));
+    hipError_t e = hipMemcpy(t.d, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      (void)hipFree(t.d);
+      return fail(h, WFE_ERR_HIP, "resample table upload: %s", hipGetErrorString(e));
+    }
+    it = h->rs_tables.emplace(key, t).first;
+  }
+  const wfe_context::RsTable& t = it->second;
+  // outputs per workgroup: their input span (opb * M / L + taps + 1) must fit the LDS buffer
+  long long opb = ((long long)wfe::kRsSpanFloats - t.taps - 2) * t.L / t.M;
+  opb = opb / 256 * 256;
+  if (opb > 2048) opb = 2048;
+  if (opb < 256) return fail(h, WFE_ERR_ARG, "resampling %d -> %d decimates too steeply", in_rate, out_rate);
+  for (const Slice& s : slices(batch)) {
+    wfe::ResampleArgs a;
+    std::memset(&a, 0, sizeof a);
+    if (pcm_channels > 0) {
+      a.pcm = static_cast<const short*>(in);
+      a.channels = pcm_channels;
+      if (!offsets) a.pcm += (long long)s.begin * row_stride;
+    } else {
+      a.wav = static_cast<const float*>(in);
+      a.channels = 1;
+      if (!offsets) a.wav += (long long)s.begin * row_stride;
+    }
+    a.offsets = offsets ? reinterpret_cast<const long long*>(offsets) + s.begin : nullptr;
+    a.lengths = lengths + s.begin;
+    a.row_stride = row_stride;
+    a.out = out + (long long)s.begin * out_stride;
+    a.out_stride = out_stride;
+    a.out_lengths = out_lengths + s.begin;
+    a.table = t.d;
+    a.L = t.L;
+    a.M = t.M;
+    a.taps = t.taps;
+    a.k0 = t.k0;
+    a.out_per_block = (int)opb;
+    HIP_TRY(h, wfe::launch_resample(a, s.count, stream));
   }
   return WFE_OK;
 }

@@ -60,4 +60,23 @@ hipError_t launch_resolve(const FrontArgs& a, int batch, double* partials, hipSt
 // augmented + padded waveform (batch, n_samples) and final lengths
 hipError_t launch_waveform(const FrontArgs& a, int batch, float* out, int* out_lengths, hipStream_t stream);
 
+// ---- resampling (CustomDataset.resample, utils/reader.py:316-319)
+constexpr int kRsSpanFloats = 14336;   // LDS floats for the input span of one workgroup
+constexpr int kRsChunkFloats = 4096;   // LDS floats for one chunk of filter rows (so L <= 4096)
+struct ResampleArgs {
+  const float* wav;              // float32 input, or
+  const short* pcm;              // interleaved 16-bit PCM
+  int channels;
+  const long long* offsets;      // optional
+  const int* lengths;            // input frames per utterance
+  long long row_stride;
+  float* out;                    // (batch, out_stride) float32, rows zero-filled behind out_lengths[b]
+  long long out_stride;
+  const int* out_lengths;        // output samples per utterance (librosa: ceil(n * out_rate / in_rate))
+  const float* table;            // [taps][L] filter, wfe_build_resample_table
+  int L, M, taps, k0;
+  int out_per_block;             // outputs per workgroup: a multiple of 256, <= 2048, span fits kRsSpanFloats
+};
+hipError_t launch_resample(const ResampleArgs& a, int batch, hipStream_t stream);
+
 }  // namespace wfe

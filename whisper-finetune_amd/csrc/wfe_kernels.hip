@@ -1133,6 +1133,77 @@ __global__ __launch_bounds__(256) void waveform_kernel(const FrontArgs a, float*
   }
 }
 
+// ------------------------------------------------------------- resampling
+// Polyphase windowed-sinc resampler (filter: wfe_tables.cpp).  One workgroup =
+// out_per_block consecutive outputs of one utterance; their input span is staged in
+// LDS once (16-bit PCM converted and mixed down on the way), the filter table
+// [taps][L] is streamed through LDS in chunks of rows shared by all waves, and every
+// thread accumulates up to 8 outputs: acc += H[j][phase] * x[base - k0 + j], float32
+// fmaf in tap order.  HBM traffic is the input once and the output once; the table
+// stays in L2.
+__global__ __launch_bounds__(256) void resample_kernel(const ResampleArgs a) {
+  __shared__ float xs[kRsSpanFloats];
+  __shared__ float hs[kRsChunkFloats];
+  constexpr int U = 8;
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const long long n0 = (long long)blockIdx.x * a.out_per_block;
+  if (n0 >= a.out_stride) return;
+  int n_out = a.out_lengths[b];
+  if (n_out < 0) n_out = 0;
+  if (n_out > a.out_stride) n_out = (int)a.out_stride;
+  float* __restrict__ o = a.out + (long long)b * a.out_stride;
+  long long n_end = n0 + a.out_per_block;
+  if (n_end > a.out_stride) n_end = a.out_stride;
+  if (n0 >= n_out) {                                   // behind the utterance: zeros
+    for (long long n = n0 + tid; n < n_end; n += 256) o[n] = 0.f;
+    return;
+  }
+  int len_in = a.lengths[b];
+  if (len_in < 0) len_in = 0;
+  const long long off = a.offsets ? a.offsets[b] : (long long)b * a.row_stride;
+  Source src;
+  src.w = a.pcm ? nullptr : a.wav + off;
+  src.pcm = a.pcm ? a.pcm + off : nullptr;
+  src.ch = a.channels;
+  const long long n_last = (n_end < n_out ? n_end : n_out) - 1;
+  const long long lo = n0 * a.M / a.L - a.k0;
+  const long long hi = n_last * a.M / a.L - a.k0 + a.taps - 1;
+  const int span = (int)(hi - lo + 1);                 // <= kRsSpanFloats (checked by the host)
+  for (int i = tid; i < span; i += 256) {
+    const long long k = lo + i;
+    xs[i] = (k >= 0 && k < len_in) ? src.at((int)k) : 0.f;
+  }
+  int phase[U], xoff[U];
+  float acc[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    long long n = n0 + tid + 256 * u;
+    if (n > n_last) n = n_last;                        // idle slots redo the last output, in bounds
+    const long long t = n * a.M;
+    const long long base = t / a.L;
+    phase[u] = (int)(t - base * a.L);
+    xoff[u] = (int)(base - a.k0 - lo);
+    acc[u] = 0.f;
+  }
+  const int rows = kRsChunkFloats / a.L;               // filter rows per chunk (>= 1)
+  for (int j0 = 0; j0 < a.taps; j0 += rows) {
+    const int r_here = (a.taps - j0 < rows) ? a.taps - j0 : rows;
+    __syncthreads();                                   // previous chunk consumed (first pass: xs written)
+    for (int i = tid; i < r_here * a.L; i += 256) hs[i] = a.table[(long long)j0 * a.L + i];
+    __syncthreads();
+    for (int r = 0; r < r_here; ++r) {
+      const float* hrow = hs + r * a.L;
+#pragma unroll
+      for (int u = 0; u < U; ++u) acc[u] = fmaf(hrow[phase[u]], xs[xoff[u] + j0 + r], acc[u]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const long long n = n0 + tid + 256 * u;
+    if (256 * u < a.out_per_block && n < n_end) o[n] = (n < n_out) ? acc[u] : 0.f;
+  }
+}
+
 // ------------------------------------------------------------- launchers
 template <int NMT, bool POWER, bool AUG, int BANK>
 static hipError_t launch_k1(const FrontArgs& a, int batch, hipStream_t stream) {
@@ -1180,6 +1251,12 @@ hipError_t launch_resolve(const FrontArgs& a, int batch, double* partials, hipSt
 hipError_t launch_waveform(const FrontArgs& a, int batch, float* out, int* out_lengths, hipStream_t stream) {
   const int gx = (a.n_samples + kBlockFrames * kHop - 1) / (kBlockFrames * kHop);
   hipLaunchKernelGGL(waveform_kernel, dim3(gx < 1 ? 1 : gx, batch), dim3(256), 0, stream, a, out, out_lengths);
+  return hipGetLastError();
+}
+
+hipError_t launch_resample(const ResampleArgs& a, int batch, hipStream_t stream) {
+  const long long gx = (a.out_stride + a.out_per_block - 1) / a.out_per_block;
+  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)(gx < 1 ? 1 : gx), batch), dim3(256), 0, stream, a);
   return hipGetLastError();
 }
 

@@ -112,3 +112,78 @@ extern "C" int wfe_build_mel_table(int32_t n_mel, float* out, uint32_t* mask14) 
           }
   return WFE_OK;
 }
+
+// ---------------------------------------------------------------- resampling
+// The reference resamples with librosa.resample (utils/reader.py:316-319,
+// res_type 'soxr_hq'): soxr is a third-party native library that is not
+// available to this build, so bit parity cannot be pinned.  The filter here is
+// librosa's other high-quality design, resampy's 'kaiser_best' -- a Kaiser
+// (beta 14.7697) windowed sinc with 64 zero crossings per side and roll-off
+// 0.94759 of the lower Nyquist -- evaluated exactly at every rational phase
+// instead of through resampy's linearly interpolated 512-per-crossing table:
+//   h(tau) = s r sinc(r s tau) I0(beta sqrt(1 - (s tau / 64)^2)) / I0(beta),   |s tau| < 64,
+// tau in input samples, s = min(1, out_rate / in_rate).  Output n sits at input
+// position n M / L (L / M = out_rate / in_rate reduced), zero-phase, zeros outside.
+namespace {
+
+const int kRsZeros = 64;
+const double kRsRolloff = 0.9475937167399596;
+const double kRsBeta = 14.769656459379492;
+
+long long gcd_ll(long long a, long long b) {
+  while (b) {
+    const long long t = a % b;
+    a = b;
+    b = t;
+  }
+  return a;
+}
+
+double bessel_i0(double x) {      // power series; x <= 15 here
+  double sum = 1.0, term = 1.0;
+  const double q = x * x / 4.0;
+  for (int k = 1; k < 200; ++k) {
+    term *= q / ((double)k * (double)k);
+    sum += term;
+    if (term < 1e-18 * sum) break;
+  }
+  return sum;
+}
+
+double rs_filter(double tau, double scale) {
+  const double x = scale * tau;
+  if (std::fabs(x) >= (double)kRsZeros) return 0.0;
+  const double a = kPi * kRsRolloff * x;
+  const double sinc = (a == 0.0) ? 1.0 : std::sin(a) / a;
+  const double t = x / (double)kRsZeros;
+  return scale * kRsRolloff * sinc * bessel_i0(kRsBeta * std::sqrt(1.0 - t * t)) / bessel_i0(kRsBeta);
+}
+
+}  // namespace
+
+extern "C" int wfe_resample_geometry(int32_t in_rate, int32_t out_rate, int32_t* L, int32_t* M, int32_t* taps,
+                                     int32_t* k0) {
+  if (in_rate < 1 || out_rate < 1 || !L || !M || !taps || !k0) return WFE_ERR_ARG;
+  const long long g = gcd_ll(in_rate, out_rate);
+  *L = (int32_t)(out_rate / g);
+  *M = (int32_t)(in_rate / g);
+  const double scale = out_rate < in_rate ? (double)out_rate / (double)in_rate : 1.0;
+  const double hw = (double)kRsZeros / scale;
+  if (hw > 1e6) return WFE_ERR_ARG;
+  *k0 = (int32_t)std::floor(hw);
+  *taps = 2 * *k0 + 2;
+  return WFE_OK;
+}
+
+// out[j * L + p] = h((j - k0) - p / L): the weight of input sample base - k0 + j for an
+// output whose position is base + p / L.  Row-major over taps so that the 64 phases a
+// wave needs for one tap lie in one short run.
+extern "C" int wfe_build_resample_table(int32_t in_rate, int32_t out_rate, float* out) {
+  int32_t L, M, taps, k0;
+  if (!out || wfe_resample_geometry(in_rate, out_rate, &L, &M, &taps, &k0) != WFE_OK) return WFE_ERR_ARG;
+  const double scale = out_rate < in_rate ? (double)out_rate / (double)in_rate : 1.0;
+  for (int j = 0; j < taps; ++j)
+    for (int p = 0; p < L; ++p)
+      out[(size_t)j * L + p] = (float)rs_filter((double)(j - k0) - (double)p / (double)L, scale);
+  return WFE_OK;
+}

@@ -138,6 +138,36 @@ class HipFrontEnd:
                                                  int(n_samples), _ptr(out), self._stream()), self._h)
         return out
 
+    # -------------------------------------------------------------- resampling
+    @staticmethod
+    def resampled_length(n: int, orig_sr: int, target_sr: int) -> int:
+        """librosa.resample's output length: int(ceil(n * (float(target_sr) / orig_sr)))."""
+        return int(np.ceil(n * (float(target_sr) / orig_sr)))
+
+    def resample(self, wav: torch.Tensor, lengths: torch.Tensor, orig_sr: int, target_sr: int,
+                 offsets: Optional[torch.Tensor] = None, channels: int = 1, out_stride: Optional[int] = None,
+                 host_lengths: Optional[Sequence[int]] = None):
+        """CustomDataset.resample (reader.py:316-319) for a batch -> (out (B, out_stride)
+        float32, out_lengths int32), both on the device; rows are zero behind their
+        length.  Input as for ``logmel`` (float32 or int16 PCM).  ``host_lengths``
+        saves the device read-back of ``lengths``."""
+        if int(orig_sr) < 1 or int(target_sr) < 1:
+            raise ValueError(f"bad sampling rates {orig_sr} -> {target_sr}")
+        batch, stride = self._geometry(wav, lengths, offsets)
+        self._check_inputs(wav, lengths, offsets, batch)
+        if host_lengths is None:
+            host_lengths = lengths.cpu().tolist()
+        out_len = [self.resampled_length(max(int(n), 0), orig_sr, target_sr) for n in host_lengths]
+        if out_stride is None:
+            out_stride = max(max(out_len, default=1), 1)
+            out_stride = (out_stride + 3) // 4 * 4                    # rows stay 16-byte aligned
+        out = torch.empty((batch, int(out_stride)), dtype=torch.float32, device=self.device)
+        out_lengths = torch.tensor([min(n, int(out_stride)) for n in out_len], dtype=torch.int32).to(self.device)
+        _lib.check(_lib.lib().wfe_resample(
+            self._h, _ptr(wav), int(channels) if wav.dtype == torch.int16 else 0, _ptr(offsets), _ptr(lengths), stride,
+            batch, int(orig_sr), int(target_sr), _ptr(out), int(out_stride), _ptr(out_lengths), self._stream()), self._h)
+        return out, out_lengths
+
     # ------------------------------------------------------------ augmentation
     _OP_DTYPE = np.dtype([("kind", "<i4"), ("i0", "<i4"), ("i1", "<i4"), ("i2", "<i4"),
                           ("f0", "<f4"), ("f1", "<f4"), ("d0", "<f8")])     # == wfe_aug_op, 32 bytes
