@@ -96,14 +96,19 @@ def add_noise(sample: np.ndarray, noise: np.ndarray, snr_db: int, randint,
 
 
 def augment(sample: np.ndarray, sample_rate: int, configs: list, rnd, noise_bank: list,
-            speed_rates=None):
+            speed_rates=None, np_rnd=None, noise_rates=None):
     """utils/reader.py:246-278: config entries in file order; a ``random()`` gate
     is drawn for every entry whose type is handled (even at prob 0), then the
     type-specific draws.  ``rnd`` is a ``random.Random`` (or the module);
     ``noise_bank`` is the list of decoded noise clips standing in for
     ``self.noise_files`` (decode itself is outside the pinned path).
-    resample / reverb entries consume their gate draw and are otherwise skipped
-    here (resample: parity unpinned; reverb: SURVEY 8f N1, next)."""
+    The resample entry (:263-267) draws its rate with ``np_rnd.choice`` (the
+    reference uses numpy's global RNG) and resamples with oracle/resample.py (PARITY
+    UNPINNED, see there); ``noise_rates`` are the native rates of the noise clips, which
+    ``librosa.load(noise_path, sr=sample_rate)`` (:323) brings to the utterance's
+    current rate.  The reverb entry consumes its gate draw and is otherwise skipped
+    (SURVEY 8f N1, next)."""
+    from . import resample as _rs
     trace = []
     for cfg in configs:
         kind, prob, prm = cfg["type"], cfg.get("prob"), cfg.get("params", {})
@@ -123,12 +128,18 @@ def augment(sample: np.ndarray, sample_rate: int, configs: list, rnd, noise_bank
             sample = volume(sample, g)
             trace.append(("volume", g))
         if kind == "resample" and rnd.random() < prob:
-            raise NotImplementedError("resample: parity unpinned, not restated on the CPU")
+            new_rate = int((np_rnd or np.random).choice(prm["new_sample_rates"]))
+            sample = _rs.resample(sample, sample_rate, new_rate)
+            sample_rate = new_rate
+            trace.append(("resample", new_rate))
         if kind == "noise" and rnd.random() < prob:
             if noise_bank:
                 j = rnd.choice(range(len(noise_bank)))
                 snr = rnd.randint(prm["min_snr_dB"], prm["max_snr_dB"])
-                sample = add_noise(sample, noise_bank[j], snr, rnd.randint)
+                noise = noise_bank[j]
+                if noise_rates is not None and int(noise_rates[j]) != int(sample_rate):
+                    noise = _rs.resample(noise, int(noise_rates[j]), int(sample_rate))
+                sample = add_noise(sample, noise, snr, rnd.randint)
                 trace.append(("noise", j, snr))
         if kind == "reverb" and rnd.random() < prob:
             pass

@@ -71,6 +71,45 @@ def test_errors_match_reference():
                          "prob": 1.0}])
     with pytest.raises(ValueError):
         p.draw(16000, 16000, random.Random(0))            # reader.py:285-286
-    p = AugmentPlanner([{"type": "resample", "params": {"new_sample_rates": [8000]}, "prob": 1.0}])
+    p = AugmentPlanner([{"type": "reverb", "params": {}, "prob": 1.0}], n_rir_files=2)
     with pytest.raises(NotImplementedError):
-        p.draw(16000, 16000, random.Random(0))
+        p.draw(16000, 16000, random.Random(0))            # not on the GPU path yet
+
+
+def test_resample_entry_splits_the_chain_into_stages():
+    """reader.py:263-267: np.random.choice(new_sample_rates) (numpy's RNG, one draw),
+    the rate changes for the entries that follow (shift in samples of the NEW rate,
+    noise clips as librosa.load(path, sr=new rate) would return them), and
+    _get_list_data returns to 16 kHz at the end (:157-158)."""
+    from wfe_amd import _lib
+    from wfe_amd.augment import HOST_RESAMPLE, resampled_length, split_stages
+    cfg = [
+        {"type": "volume", "params": {"min_gain_dBFS": 3, "max_gain_dBFS": 3}, "prob": 1.0},
+        {"type": "resample", "params": {"new_sample_rates": [8000, 32000, 44100]}, "prob": 1.0},
+        {"type": "noise", "params": {"min_snr_dB": 10, "max_snr_dB": 10}, "prob": 1.0},
+        {"type": "shift", "params": {"min_shift_ms": 5, "max_shift_ms": 5}, "prob": 1.0},
+    ]
+    p = AugmentPlanner(cfg, noise_lengths=[480000], noise_rates=[48000])
+    g = np.random.default_rng(5)
+    want_rate = int(np.random.default_rng(5).choice([8000, 32000, 44100]))
+    rnd = random.Random(1)
+    ops, n = p.draw(16000, 16000, rnd, g)
+    assert n == resampled_length(16000, 16000, want_rate)
+    assert [o[0] for o in ops] == [_lib.AUG_VOLUME, HOST_RESAMPLE, _lib.AUG_NOISE, _lib.AUG_SHIFT]
+    assert ops[1][1] == want_rate and ops[3][1] == int(5 * want_rate / 1000)
+    # the 10 s / 48 kHz noise clip is longer than the utterance at any of the rates: a start offset was drawn
+    r = random.Random(1)
+    r.random(), r.randint(3, 3)            # volume gate + gain
+    r.random()                             # resample gate (the rate comes from numpy's RNG)
+    r.random(), r.choice(range(1)), r.randint(10, 10)      # noise gate, clip, SNR
+    assert ops[2][2] == r.randint(0, resampled_length(480000, 48000, want_rate) - n)
+    st = split_stages(ops, 16000, 16000, 16000)
+    assert [(s["sr"], s["next_sr"], len(s["ops"])) for s in st] == [(16000, want_rate, 1), (want_rate, 16000, 2),
+                                                                    (16000, None, 0)]
+    assert st[1]["len_in"] == n and st[2]["len_in"] == resampled_length(n, want_rate, 16000)
+    # a 44.1 kHz file without augmentation: one resampling stage, then the log-mel stage
+    st = split_stages([], 44100, 44100, 16000)
+    assert [(s["sr"], s["len_in"], s["next_sr"]) for s in st] == [(44100, 44100, 16000), (16000, 16000, None)]
+    # same-rate choice is not a stage boundary
+    p2 = AugmentPlanner([{"type": "resample", "params": {"new_sample_rates": [16000]}, "prob": 1.0}])
+    assert p2.draw(1000, 16000, random.Random(0), np.random.default_rng(0)) == ([], 1000)

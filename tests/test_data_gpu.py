@@ -102,3 +102,64 @@ def test_specaug_and_eval_collator(tmp_path):
     b2 = ev([plain[0], plain[1]])
     want = ol.logmel_f32([_read_wav(r["audio"]["path"]) for r in recs[:2]], n_mel=80)
     assert np.abs(b2["input_features"].cpu().numpy() - want).max() <= 1e-4
+
+
+def test_other_sampling_rates_end_to_end(tmp_path):
+    """Files that are not at 16 kHz (reader.py:157-158), a resample augmentation
+    (:263-267) and noise clips at a third rate (:323), through CustomDataset -> collator
+    with the GPU resampler, against the oracle chain.  Resampling is PARITY UNPINNED
+    w.r.t. the reference's soxr filter (oracle/resample.py); the tolerance here is the
+    log-mel bar, 1e-4, against the oracle's restated filter."""
+    from oracle import resample as rs
+    from wfe_amd import data as wd
+    rng = np.random.default_rng(21)
+    (tmp_path / "noise").mkdir()
+    for j in range(2):
+        _write_wav(tmp_path / "noise" / f"n{j}.wav", cases.noise_clip(j, 1.5 + j)[:int(16000 * (1.5 + j))], sr=22050)
+    recs, rates = [], [44100, 8000, 16000, 48000, 16000]
+    for i, (sr, dur) in enumerate(zip(rates, [2.0, 3.1, 1.7, 29.0, 4.0])):
+        p = tmp_path / f"a{i}.wav"
+        t = np.arange(int(dur * sr)) / sr
+        x = 0.2 * np.sin(2 * np.pi * (300 + 150 * i) * t) * (0.6 + 0.4 * np.sin(2 * np.pi * 2 * t)) \
+            + 0.02 * rng.standard_normal(len(t))
+        _write_wav(p, x, sr=sr)
+        recs.append({"audio": {"path": str(p)}, "sentence": f"utt {i}", "duration": dur})
+    mf = tmp_path / "list.json"
+    mf.write_text("\n".join(json.dumps(r) for r in recs))
+    proc = stubs.StubProcessor(n_mel=80)
+    read = lambda r: _read_wav(r["audio"]["path"])                      # noqa: E731
+
+    # 1. no augmentation: decode -> resample to 16 kHz -> log-mel
+    ds = wd.CustomDataset(str(mf), proc)
+    coll = wd.DataCollatorSpeechSeq2SeqWithPadding(processor=proc)
+    got = coll([ds[i] for i in range(len(recs))])["input_features"].numpy()
+    want = [rs.resample(read(r), sr, 16000) if sr != 16000 else read(r) for r, sr in zip(recs, rates)]
+    err = np.abs(got - ol.logmel_f32(want, n_mel=80)).reshape(len(recs), -1).max(axis=1)
+    print("multi-rate max-abs-err:", err)
+    assert (err <= 1e-4).all(), err
+
+    # 2. with the shipped entry order and everything firing, incl. the resample augmentation
+    cfg = [
+        {"type": "resample", "params": {"new_sample_rates": [8000, 32000, 44100]}, "prob": 1.0},
+        {"type": "noise", "params": {"min_snr_dB": 10, "max_snr_dB": 50, "noise_dir": str(tmp_path / "noise")}, "prob": 1.0},
+        {"type": "speed", "params": {"min_speed_rate": 0.9, "max_speed_rate": 1.1, "num_rates": 3}, "prob": 1.0},
+        {"type": "shift", "params": {"min_shift_ms": -5, "max_shift_ms": 5}, "prob": 1.0},
+        {"type": "volume", "params": {"min_gain_dBFS": -15, "max_gain_dBFS": 15}, "prob": 1.0},
+    ]
+    cfgp = tmp_path / "aug.json"
+    cfgp.write_text(json.dumps(cfg))
+    ds = wd.CustomDataset(str(mf), proc, augment_config_path=str(cfgp))
+    coll = wd.DataCollatorSpeechSeq2SeqWithPadding(processor=proc)
+    random.seed(7)
+    np.random.seed(7)
+    got = coll([ds[i] for i in range(len(recs))])["input_features"].numpy()
+    random.seed(7)
+    np.random.seed(7)
+    bank = [_read_wav(p) for p in ds.noise_files]
+    want = []
+    for r, sr in zip(recs, rates):
+        aug, sr2, trace = oa.augment(read(r).copy(), sr, cfg, random, bank, np_rnd=np.random, noise_rates=[22050, 22050])
+        want.append(rs.resample(aug, sr2, 16000) if sr2 != 16000 else aug)
+    err = np.abs(got - ol.logmel_f32(want, n_mel=80)).reshape(len(recs), -1).max(axis=1)
+    print("multi-rate augmented max-abs-err:", err)
+    assert (err <= 1e-4).all(), err

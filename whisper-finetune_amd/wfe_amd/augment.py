@@ -15,9 +15,13 @@ Draw order restated from the reference:
   * noise:  only when noise clips exist: ``random.choice(files)``,
             ``random.randint(min_snr, max_snr)`` and, when the clip is longer than
             the sample, ``random.randint(0, len_noise - len_sample)`` (reader.py:337);
-  * resample / reverb: gate drawn; firing raises NotImplementedError (SURVEY 8f N1/N2:
-    not part of the GPU chain yet) -- with the shipped config (resample prob 0.0,
-    placeholder rir_dir) neither can fire.
+  * resample: ``np.random.choice(new_sample_rates)`` (numpy's global RNG, reader.py:265); the
+            sample rate changes for every later entry (shift samples, noise clips loaded at the
+            new rate).  A host-only marker op (HOST_RESAMPLE, rate) splits the chain into STAGES
+            (``split_stages``): each stage is a fused chain at one rate, stages are joined by the
+            GPU resampler (include/wfe.h wfe_resample), the last one ends at the target rate;
+  * reverb: gate drawn; firing raises NotImplementedError (not part of the
+            GPU chain yet) -- with the shipped config (placeholder rir_dir) it cannot fire.
 """
 from __future__ import annotations
 
@@ -29,20 +33,54 @@ import numpy as np
 from ._lib import AUG_NOISE, AUG_SHIFT, AUG_SPEED, AUG_VOLUME
 
 Op = Tuple[int, int, int, int, float]      # (kind, i0, i1, i2, f0) -- see wfe_aug_op
+HOST_RESAMPLE = 100                        # (HOST_RESAMPLE, new_rate, 0, 0, 0.0): never sent to the device
+
+
+def resampled_length(n: int, orig_sr: int, target_sr: int) -> int:
+    """librosa.resample / librosa.load: int(ceil(n * (float(target_sr) / orig_sr)))."""
+    return int(n) if int(orig_sr) == int(target_sr) else int(np.ceil(n * (float(target_sr) / orig_sr)))
+
+
+def split_stages(ops: Sequence[Op], length: int, sample_rate: int, target_rate: int):
+    """-> [{"sr", "ops", "len_in", "len_out", "next_sr"}]: ``ops`` (device ops only) run on
+    ``len_in`` samples at ``sr`` and leave ``len_out``; the result is resampled to
+    ``next_sr`` (None after the last stage, which is always at ``target_rate``:
+    reader.py:157-158)."""
+    stages, cur, sr, n = [], [], int(sample_rate), int(length)
+    n_in = n
+    for op in list(ops) + [(HOST_RESAMPLE, int(target_rate), 0, 0, 0.0)]:
+        if op[0] == HOST_RESAMPLE:
+            new_sr = int(op[1])
+            if new_sr != sr:
+                stages.append({"sr": sr, "ops": cur, "len_in": n_in, "len_out": n, "next_sr": new_sr})
+                n = resampled_length(n, sr, new_sr)
+                cur, sr, n_in = [], new_sr, n
+            continue
+        if op[0] == AUG_SPEED:
+            n = int(op[1])
+        cur.append(op)
+    stages.append({"sr": sr, "ops": cur, "len_in": n_in, "len_out": n, "next_sr": None})
+    return stages
 
 
 class AugmentPlanner:
     def __init__(self, configs: Sequence[dict], noise_lengths: Optional[Sequence[int]] = None,
-                 n_rir_files: int = 0):
+                 n_rir_files: int = 0, noise_rates: Optional[Sequence[int]] = None):
+        """``noise_lengths`` / ``noise_rates``: length and native sampling rate of every
+        noise clip (rates default to "the utterance's own rate": no resampling of noise)."""
         self.configs = list(configs)
         self.noise_lengths = list(noise_lengths) if noise_lengths else []
+        self.noise_rates = list(noise_rates) if noise_rates else None
         self.n_rir_files = int(n_rir_files)
         self.speed_rates = None            # lazily built, like CustomDataset.speed_rates (reader.py:249-252)
 
-    def draw(self, length: int, sample_rate: int, rnd=_random) -> Tuple[List[Op], int]:
-        """Decisions for one utterance of ``length`` samples -> (ops, final length)."""
+    def draw(self, length: int, sample_rate: int, rnd=_random, np_rnd=None) -> Tuple[List[Op], int]:
+        """Decisions for one utterance of ``length`` samples -> (ops, final length at the
+        final rate).  ``np_rnd``: the numpy generator the resample entry draws from
+        (default: numpy's global one, as the reference)."""
         ops: List[Op] = []
         n = int(length)
+        sample_rate = int(sample_rate)
         for cfg in self.configs:
             kind, prob, prm = cfg["type"], cfg.get("prob"), cfg.get("params", {})
             if kind == "speed" and rnd.random() < prob:
@@ -69,12 +107,18 @@ class AugmentPlanner:
                 gain = rnd.randint(prm["min_gain_dBFS"], prm["max_gain_dBFS"])
                 ops.append((AUG_VOLUME, 0, 0, gain, float(np.float32(10. ** (gain / 20.)))))
             if kind == "resample" and rnd.random() < prob:
-                raise NotImplementedError("resample augmentation is not part of the GPU chain yet (SURVEY 8f N2)")
+                new_rate = int((np_rnd or np.random).choice(prm["new_sample_rates"]))
+                if new_rate != sample_rate:
+                    ops.append((HOST_RESAMPLE, new_rate, 0, 0, 0.0))
+                    n = resampled_length(n, sample_rate, new_rate)
+                    sample_rate = new_rate
             if kind == "noise" and rnd.random() < prob:
                 if self.noise_lengths:
                     j = rnd.choice(range(len(self.noise_lengths)))
                     snr = rnd.randint(prm["min_snr_dB"], prm["max_snr_dB"])
                     ln = self.noise_lengths[j]
+                    if self.noise_rates is not None:                # librosa.load(noise_path, sr=sample_rate)
+                        ln = resampled_length(ln, self.noise_rates[j], sample_rate)
                     start = rnd.randint(0, ln - n) if ln > n else 0
                     ops.append((AUG_NOISE, j, start, snr, 0.0))
             if kind == "reverb" and rnd.random() < prob:

@@ -35,7 +35,7 @@ from typing import Any, List, Optional
 import numpy as np
 import torch
 
-from .augment import AugmentPlanner
+from .augment import HOST_RESAMPLE, AugmentPlanner, split_stages
 
 try:                                    # audio decode is host I/O, outside the GPU path
     import soundfile as _sf
@@ -252,6 +252,7 @@ class CustomDataset(torch.utils.data.Dataset):
         self.noise_files: Optional[List[str]] = None
         self.rir_files: Optional[List[str]] = None
         self.noise_clips: List[np.ndarray] = []     # decoded once, uploaded by the collator
+        self.noise_rates: List[int] = []            # their native sampling rates
         self.planner: Optional[AugmentPlanner] = None
         if augment_config_path:
             with open(augment_config_path, "r", encoding="utf-8") as f:
@@ -281,13 +282,12 @@ class CustomDataset(torch.utils.data.Dataset):
                 clip = clip.T
                 if clip.ndim > 1:
                     clip = clip.mean(axis=0)
-                if sr != self.sample_rate:
-                    raise NotImplementedError(f"noise clip {p} is {sr} Hz: resampling is not on the GPU path yet")
                 self.noise_clips.append(np.ascontiguousarray(clip, dtype=np.float32))
+                self.noise_rates.append(int(sr))     # resampled on the GPU to whatever rate an utterance has (reader.py:323)
             self.planner = AugmentPlanner(self.augment_configs, [len(c) for c in self.noise_clips],
-                                          len(self.rir_files or []))
+                                          len(self.rir_files or []), noise_rates=self.noise_rates)
             if self.noise_clips:
-                _NOISE_CLIPS[id(processor)] = self.noise_clips
+                _NOISE_CLIPS[id(processor)] = (self.noise_clips, self.noise_rates)
 
     @staticmethod
     def _load_wav_files(data_dir):
@@ -342,10 +342,7 @@ class CustomDataset(torch.utils.data.Dataset):
         ops = []
         if self.augment_configs:
             ops, _ = self.planner.draw(n_frames, sr)
-        if self.sample_rate != sr:
-            raise NotImplementedError(f"{path} is {sr} Hz: resampling to {self.sample_rate} Hz is not on the GPU "
-                                      "path yet (SURVEY 8f N2)")
-        return rec["id"] if "id" in rec else path, sample, sr, transcript, language, ops
+        return rec["id"] if "id" in rec else path, sample, int(sr), transcript, language, ops
 
     def _decode(self, audio: dict):
         """reader.py:142-148.  16-bit PCM stays int16 (see read_pcm16) when the
@@ -384,7 +381,9 @@ class CustomDataset(torch.utils.data.Dataset):
                     labels = self.processor.tokenizer(transcript).input_ids
             else:
                 labels = [self.startoftranscript, self.nocaptions, self.endoftext]
-            item = {"waveform": sample, "aug_ops": ops, "labels": labels, "id": audio_id, "specaug": False}
+            # "sample_rate": the file's own rate; the collator resamples on the GPU (reader.py:157-158)
+            item = {"waveform": sample, "aug_ops": ops, "labels": labels, "id": audio_id, "specaug": False,
+                    "sample_rate": sr, "target_rate": self.sample_rate}
             if self.augment_configs and self.spec_aug:
                 if random.random() < self.spec_aug.get("prob"):
                     item["specaug"] = self._draw_spec_augmentation()
@@ -469,18 +468,70 @@ class DataCollatorSpeechSeq2SeqWithPadding:
     keep_prompt = False
     with_ids = False
 
-    def __init__(self, processor: Any, device=None, device_output: Optional[bool] = None, noise_clips=None):
+    def __init__(self, processor: Any, device=None, device_output: Optional[bool] = None, noise_clips=None,
+                 noise_rates=None):
         self.processor = processor
         self.device = device
         self.device_output = (os.environ.get("WFE_DEVICE_OUTPUT", "0") == "1") if device_output is None \
             else bool(device_output)
-        self._noise_src = noise_clips
-        self._noise_bank = None
+        self._noise_src = (noise_clips, noise_rates) if noise_clips is not None else None
+        self._noise_banks: dict = {}
         self._packer = None
 
-    def set_noise_clips(self, clips):
-        """The decoded noise clips of ``CustomDataset.noise_clips`` (uploaded once)."""
-        self._noise_src, self._noise_bank = clips, None
+    def set_noise_clips(self, clips, rates=None):
+        """The decoded noise clips of ``CustomDataset.noise_clips`` and their native
+        rates (uploaded once; resampled on the GPU per utterance rate on first use)."""
+        self._noise_src, self._noise_banks = (clips, rates), {}
+
+    def _bank(self, fe, rate: int):
+        """Noise clips at ``rate``: what ``librosa.load(noise_path, sr=rate)`` hands
+        add_noise (reader.py:323), resident on the device."""
+        from .frontend import NoiseBank
+        rate = int(rate)
+        if rate in self._noise_banks:
+            return self._noise_banks[rate]
+        src = self._noise_src if self._noise_src is not None else _NOISE_CLIPS.get(id(self.processor))
+        bank = None
+        if src and src[0]:
+            clips, rates = src
+            if rates is None or all(int(r) == rate for r in rates):
+                bank = NoiseBank(clips, fe.device)
+            else:
+                on_dev = []
+                for c, r in zip(clips, rates):
+                    t = torch.from_numpy(np.ascontiguousarray(c, dtype=np.float32)).to(fe.device)
+                    if int(r) != rate:
+                        ln = torch.tensor([len(c)], dtype=torch.int32, device=fe.device)
+                        o, _ = fe.resample(t[None], ln, int(r), rate, host_lengths=[len(c)])
+                        t = o[0, :fe.resampled_length(len(c), int(r), rate)]
+                    on_dev.append(t)
+                bank = NoiseBank.from_tensors(on_dev, fe.device)
+        self._noise_banks[rate] = bank
+        return bank
+
+    def _staged(self, fe, group: List[dict], stages: List[list], n_samples: int) -> torch.Tensor:
+        """Utterances whose chain spans more than one sampling rate (a file that is not
+        at the target rate, or a resample augmentation): every stage but the last is
+        [fused chain -> waveform] -> GPU resampler, the last is the fused
+        chain + log-mel launch at the target rate."""
+        first_has_ops = any(st[0]["ops"] for st in stages)
+        wav, off, lens, ch = self._packer.pack([it["waveform"] for it in group], force_float=first_has_ops)
+        n_stage = len(stages[0])
+        for k in range(n_stage - 1):
+            sr, nxt = stages[0][k]["sr"], stages[0][k]["next_sr"]
+            plans = [st[k]["ops"] for st in stages]
+            host_lens = [st[k]["len_out"] for st in stages]
+            if any(plans):
+                width = (max(max(host_lens), 1) + 3) // 4 * 4
+                wav, lens = fe.augment_waveform(wav, lens, plans, self._bank(fe, sr), n_samples=width, offsets=off)
+                off, ch = None, 1
+            wav, lens = fe.resample(wav, lens, sr, nxt, offsets=off, channels=ch, host_lengths=host_lens)
+            off, ch = None, 1
+        plans = [st[-1]["ops"] for st in stages]
+        if any(plans):
+            return fe.augment_logmel(wav, lens, plans, self._bank(fe, stages[0][-1]["sr"]), n_samples=n_samples,
+                                     offsets=off, channels=ch)
+        return fe.logmel(wav, lens, n_samples=n_samples, offsets=off, channels=ch)
 
     def _features(self, items):
         fe_cfg = self.processor.feature_extractor
@@ -494,20 +545,39 @@ class DataCollatorSpeechSeq2SeqWithPadding:
                                    "worker cannot use the GPU -- launch with --num_workers 0 (host decode is "
                                    "parallelised inside CustomDataset.__getitems__)")
             from .feature_extractor import front_end
-            from .frontend import NoiseBank, RaggedPacker
+            from .frontend import RaggedPacker
             fe = front_end(n_mel, self.device)
             if self._packer is None or self._packer.device != fe.device:
                 self._packer = RaggedPacker(fe.device, int(os.environ.get("WFE_DECODE_THREADS", "8")))
-            flat, off, lens, ch = self._packer.pack([items[i]["waveform"] for i in gpu_items])
-            plans = [items[i].get("aug_ops") or [] for i in gpu_items]
-            if any(plans):
-                src = self._noise_src if self._noise_src is not None else _NOISE_CLIPS.get(id(self.processor))
-                if self._noise_bank is None and src:
-                    self._noise_bank = NoiseBank(src, fe.device)
-                out = fe.augment_logmel(flat, lens, plans, self._noise_bank, n_samples=n_samples, offsets=off,
-                                        channels=ch)
-            else:
-                out = fe.logmel(flat, lens, n_samples=n_samples, offsets=off, channels=ch)
+            target = int(fe_cfg.sampling_rate)
+            simple, staged = [], {}
+            for j, i in enumerate(gpu_items):
+                it = items[i]
+                ops, sr = it.get("aug_ops") or [], int(it.get("sample_rate", target))
+                if sr == int(it.get("target_rate", target)) and not any(op[0] == HOST_RESAMPLE for op in ops):
+                    simple.append(j)
+                else:
+                    st = split_stages(ops, it["waveform"].shape[0], sr, int(it.get("target_rate", target)))
+                    staged.setdefault(tuple(s["sr"] for s in st), []).append((j, st))
+            out = None
+            if simple:
+                sel = [items[gpu_items[j]] for j in simple]
+                flat, off, lens, ch = self._packer.pack([it["waveform"] for it in sel])
+                plans = [it.get("aug_ops") or [] for it in sel]
+                if any(plans):
+                    out = fe.augment_logmel(flat, lens, plans, self._bank(fe, target), n_samples=n_samples, offsets=off,
+                                            channels=ch)
+                else:
+                    out = fe.logmel(flat, lens, n_samples=n_samples, offsets=off, channels=ch)
+            if staged:
+                whole = torch.empty((len(gpu_items), n_mel, frames), dtype=torch.float32, device=fe.device)
+                if simple:
+                    whole[torch.tensor(simple, device=fe.device)] = out
+                for members in staged.values():
+                    part = self._staged(fe, [items[gpu_items[j]] for j, _ in members], [st for _, st in members],
+                                        n_samples)
+                    whole[torch.tensor([j for j, _ in members], device=fe.device)] = part
+                out = whole
             for j, i in enumerate(gpu_items):             # reader.py:355-389 on the (1, M, T) layout
                 sa = items[i].get("specaug")
                 if sa:

@@ -38,6 +38,19 @@ class NoiseBank:
         self.offsets = torch.from_numpy(off).to(device)
         self.n = len(clips)
 
+    @classmethod
+    def from_tensors(cls, clips: Sequence[torch.Tensor], device: torch.device) -> "NoiseBank":
+        """Clips that already live on the device (e.g. resampled there)."""
+        self = cls.__new__(cls)
+        self.lengths = [int(c.numel()) for c in clips]
+        off = np.zeros(len(clips) + 1, dtype=np.int64)
+        off[1:] = np.cumsum(self.lengths)
+        self.data = torch.cat([c.reshape(-1).to(device=device, dtype=torch.float32) for c in clips]) if clips else \
+            torch.zeros(0, dtype=torch.float32, device=device)
+        self.offsets = torch.from_numpy(off).to(device)
+        self.n = len(clips)
+        return self
+
 
 class HipFrontEnd:
     def __init__(self, n_mel: int = 80, device: int | torch.device | str | None = None,
@@ -272,11 +285,11 @@ class RaggedPacker:
             return f.reshape(-1) if f.ndim == 1 or f.shape[1] == 1 else np.mean(f.T, axis=0)
         return np.asarray(w, dtype=np.float32).reshape(-1)
 
-    def pack(self, waves: Sequence[np.ndarray]):
+    def pack(self, waves: Sequence[np.ndarray], force_float: bool = False):
         """-> (flat device tensor, int64 offsets, int32 lengths, channels); offsets
         count elements of ``flat``, lengths count frames."""
         n = len(waves)
-        pcm = n > 0 and all(getattr(w, "dtype", None) == np.int16 for w in waves)
+        pcm = n > 0 and not force_float and all(getattr(w, "dtype", None) == np.int16 for w in waves)
         ch = 1
         if pcm:
             chans = {1 if w.ndim == 1 else w.shape[1] for w in waves}
