@@ -154,6 +154,19 @@ int wfe_resample(wfe_handle h, const void* in, int32_t pcm_channels, const int64
                  const int32_t* lengths, int64_t row_stride, int32_t batch, int32_t in_rate, int32_t out_rate,
                  float* out, int64_t out_stride, const int32_t* out_lengths, void* stream);
 
+/* CustomDataset.add_reverb (utils/reader.py:342-348) for a batch:
+ * scipy.signal.fftconvolve(sample, rir, mode='same') as a direct float32 sum, then
+ * y * (max|sample| / max|y|).  Utterances with rir_index[b] < 0 are copied through.
+ *   wav / offsets / lengths / row_stride   as wfe_logmel (float32 only)
+ *   rir, rir_offsets   device float32 impulse responses back to back and their
+ *                      int64[n_rir + 1] prefix offsets (already at the utterances' rate:
+ *                      librosa.load(rir_file, sr=sample_rate))
+ *   rir_index          device int32[batch]
+ *   out                device float32 (batch, out_stride), rows zero behind lengths[b] */
+int wfe_reverb(wfe_handle h, const float* wav, const int64_t* offsets, const int32_t* lengths,
+               int64_t row_stride, int32_t batch, const float* rir, const int64_t* rir_offsets, int32_t n_rir,
+               const int32_t* rir_index, float* out, int64_t out_stride, void* stream);
+
 /* The augmented, padded waveform itself, (batch, n_samples) float32: what
  * CustomDataset._get_list_data returns (utils/reader.py:134-162) after pad/trim.
  * Used by the parity tests of the augmentation stages. */

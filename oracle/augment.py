@@ -95,8 +95,19 @@ def add_noise(sample: np.ndarray, noise: np.ndarray, snr_db: int, randint,
     return sample
 
 
+def add_reverb(sample: np.ndarray, rir: np.ndarray) -> np.ndarray:
+    """utils/reader.py:342-348 with the impulse response already decoded (and at the
+    utterance's rate): scipy.signal.fftconvolve(mode='same') -- the reference's own
+    third-party call, installed here (scipy 1.15.3) -- then the peak normalisation.
+    Pinned against scipy by construction; the three lines around it are restated."""
+    from scipy.signal import fftconvolve
+    out = fftconvolve(sample, rir, mode="same")
+    max_rate = np.max(np.abs(sample)) / np.max(np.abs(out))
+    return out * max_rate
+
+
 def augment(sample: np.ndarray, sample_rate: int, configs: list, rnd, noise_bank: list,
-            speed_rates=None, np_rnd=None, noise_rates=None):
+            speed_rates=None, np_rnd=None, noise_rates=None, rir_bank=None, rir_rates=None):
     """utils/reader.py:246-278: config entries in file order; a ``random()`` gate
     is drawn for every entry whose type is handled (even at prob 0), then the
     type-specific draws.  ``rnd`` is a ``random.Random`` (or the module);
@@ -106,8 +117,8 @@ def augment(sample: np.ndarray, sample_rate: int, configs: list, rnd, noise_bank
     reference uses numpy's global RNG) and resamples with oracle/resample.py (PARITY
     UNPINNED, see there); ``noise_rates`` are the native rates of the noise clips, which
     ``librosa.load(noise_path, sr=sample_rate)`` (:323) brings to the utterance's
-    current rate.  The reverb entry consumes its gate draw and is otherwise skipped
-    (SURVEY 8f N1, next)."""
+    current rate.  ``rir_bank`` / ``rir_rates``: the decoded impulse responses standing
+    in for ``self.rir_files`` (:274-277)."""
     from . import resample as _rs
     trace = []
     for cfg in configs:
@@ -142,5 +153,11 @@ def augment(sample: np.ndarray, sample_rate: int, configs: list, rnd, noise_bank
                 sample = add_noise(sample, noise, snr, rnd.randint)
                 trace.append(("noise", j, snr))
         if kind == "reverb" and rnd.random() < prob:
-            pass
+            if rir_bank:
+                j = rnd.choice(range(len(rir_bank)))
+                rir = rir_bank[j]
+                if rir_rates is not None and int(rir_rates[j]) != int(sample_rate):
+                    rir = _rs.resample(rir, int(rir_rates[j]), int(sample_rate))
+                sample = add_reverb(sample, rir)
+                trace.append(("reverb", j))
     return sample, sample_rate, trace

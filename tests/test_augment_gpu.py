@@ -224,3 +224,36 @@ def test_extreme_speed_rates(fe, rate):
     assert got_len[0] == len(want)
     assert np.array_equal(got[0, :k], want[:k]), np.abs(got[0, :k] - want[:k]).max()
     assert not got[0, k:].any()
+
+
+def _rir(seed, n):
+    """A synthetic room impulse response: direct path + exponentially decaying noise."""
+    rng = np.random.default_rng(seed)
+    h = rng.standard_normal(n) * np.exp(-np.arange(n) / (0.25 * n))
+    h[0] = 1.0
+    return (0.5 * h).astype(np.float32)
+
+
+def test_reverb_matches_scipy_fftconvolve(fe):
+    """wfe_reverb against the reference's add_reverb (reader.py:342-348) restated around
+    the reference's own scipy.signal.fftconvolve call.  The direct float32 sum and
+    scipy's float32 FFT differ by rounding only: |err| <= 3e-6 * max|y| * sqrt(taps / 64)
+    (measured well below), lengths unchanged, untouched rows copied through."""
+    from wfe_amd.frontend import NoiseBank, pack_ragged
+    rirs = [_rir(0, 1), _rir(1, 300), _rir(2, 513), _rir(3, 4000), _rir(4, 1600)]
+    waves = [cases.bench_clip(30 + i, n) for i, n in enumerate((48000, 5000, 2049, 20000, 1000, 7777))]
+    index = [3, 1, 2, 4, 4, -1]                       # a 1600-tap response on a 1000-sample utterance; one pass-through
+    flat, off, lens = pack_ragged(waves, fe.device)
+    out = fe.reverb(flat, lens, NoiseBank(rirs, fe.device), index, offsets=off)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    for i, (w, j) in enumerate(zip(waves, index)):
+        want = oa.add_reverb(w.copy(), rirs[j]) if j >= 0 else w
+        assert want.dtype == np.float32
+        err = np.abs(out[i, :len(w)] - want).max()
+        bound = 0.0 if j < 0 else 3e-6 * np.abs(want).max() * max(1.0, np.sqrt(len(rirs[j]) / 64))
+        assert err <= bound, (i, err, bound)
+        assert not out[i, len(w):].any()
+    single = fe.reverb(flat, lens, NoiseBank(rirs, fe.device), [0] * 6, offsets=off).cpu().numpy()
+    for i, w in enumerate(waves):                     # a one-tap response of 0.5: y = 0.5 x, rescaled back to x
+        assert np.abs(single[i, :len(w)] - w).max() <= 1e-7

@@ -71,9 +71,12 @@ def test_errors_match_reference():
                          "prob": 1.0}])
     with pytest.raises(ValueError):
         p.draw(16000, 16000, random.Random(0))            # reader.py:285-286
+    from wfe_amd.augment import HOST_REVERB
     p = AugmentPlanner([{"type": "reverb", "params": {}, "prob": 1.0}], n_rir_files=2)
-    with pytest.raises(NotImplementedError):
-        p.draw(16000, 16000, random.Random(0))            # not on the GPU path yet
+    r = random.Random(0)
+    r.random()
+    assert p.draw(16000, 16000, random.Random(0)) == ([(HOST_REVERB, r.choice(range(2)), 0, 0, 0.0)], 16000)
+    assert AugmentPlanner([{"type": "reverb", "params": {}, "prob": 1.0}]).draw(16000, 16000, random.Random(0)) == ([], 16000)
 
 
 def test_resample_entry_splits_the_chain_into_stages():
@@ -82,7 +85,7 @@ def test_resample_entry_splits_the_chain_into_stages():
     noise clips as librosa.load(path, sr=new rate) would return them), and
     _get_list_data returns to 16 kHz at the end (:157-158)."""
     from wfe_amd import _lib
-    from wfe_amd.augment import HOST_RESAMPLE, resampled_length, split_stages
+    from wfe_amd.augment import HOST_RESAMPLE, HOST_REVERB, resampled_length, split_stages
     cfg = [
         {"type": "volume", "params": {"min_gain_dBFS": 3, "max_gain_dBFS": 3}, "prob": 1.0},
         {"type": "resample", "params": {"new_sample_rates": [8000, 32000, 44100]}, "prob": 1.0},
@@ -104,12 +107,17 @@ def test_resample_entry_splits_the_chain_into_stages():
     r.random(), r.choice(range(1)), r.randint(10, 10)      # noise gate, clip, SNR
     assert ops[2][2] == r.randint(0, resampled_length(480000, 48000, want_rate) - n)
     st = split_stages(ops, 16000, 16000, 16000)
-    assert [(s["sr"], s["next_sr"], len(s["ops"])) for s in st] == [(16000, want_rate, 1), (want_rate, 16000, 2),
-                                                                    (16000, None, 0)]
+    assert [(s["sr"], s["post"], len(s["ops"])) for s in st] == [(16000, ("resample", want_rate), 1),
+                                                                 (want_rate, ("resample", 16000), 2), (16000, None, 0)]
     assert st[1]["len_in"] == n and st[2]["len_in"] == resampled_length(n, want_rate, 16000)
     # a 44.1 kHz file without augmentation: one resampling stage, then the log-mel stage
     st = split_stages([], 44100, 44100, 16000)
-    assert [(s["sr"], s["len_in"], s["next_sr"]) for s in st] == [(44100, 44100, 16000), (16000, 16000, None)]
+    assert [(s["sr"], s["len_in"], s["post"]) for s in st] == [(44100, 44100, ("resample", 16000)), (16000, 16000, None)]
+    # a reverb entry ends a stage without changing rate or length
+    st = split_stages([(_lib.AUG_VOLUME, 0, 0, 3, 1.4), (HOST_REVERB, 1, 0, 0, 0.0), (_lib.AUG_SHIFT, 8, 0, 0, 0.0)],
+                      500, 16000, 16000)
+    assert [(s["sr"], s["post"], len(s["ops"]), s["len_in"]) for s in st] == [(16000, ("reverb", 1), 1, 500),
+                                                                              (16000, None, 1, 500)]
     # same-rate choice is not a stage boundary
     p2 = AugmentPlanner([{"type": "resample", "params": {"new_sample_rates": [16000]}, "prob": 1.0}])
     assert p2.draw(1000, 16000, random.Random(0), np.random.default_rng(0)) == ([], 1000)

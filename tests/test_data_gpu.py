@@ -138,10 +138,15 @@ def test_other_sampling_rates_end_to_end(tmp_path):
     print("multi-rate max-abs-err:", err)
     assert (err <= 1e-4).all(), err
 
-    # 2. with the shipped entry order and everything firing, incl. the resample augmentation
+    # 2. with the shipped entry order and everything firing, incl. the resample and reverb entries
+    (tmp_path / "rir").mkdir()
+    for j in range(2):
+        h = np.random.default_rng(40 + j).standard_normal(2000 + 777 * j) * np.exp(-np.arange(2000 + 777 * j) / 500.0)
+        _write_wav(tmp_path / "rir" / f"r{j}.wav", 0.3 * h / np.abs(h).max(), sr=16000)
     cfg = [
         {"type": "resample", "params": {"new_sample_rates": [8000, 32000, 44100]}, "prob": 1.0},
         {"type": "noise", "params": {"min_snr_dB": 10, "max_snr_dB": 50, "noise_dir": str(tmp_path / "noise")}, "prob": 1.0},
+        {"type": "reverb", "params": {"rir_dir": str(tmp_path / "rir")}, "prob": 1.0},
         {"type": "speed", "params": {"min_speed_rate": 0.9, "max_speed_rate": 1.1, "num_rates": 3}, "prob": 1.0},
         {"type": "shift", "params": {"min_shift_ms": -5, "max_shift_ms": 5}, "prob": 1.0},
         {"type": "volume", "params": {"min_gain_dBFS": -15, "max_gain_dBFS": 15}, "prob": 1.0},
@@ -156,9 +161,12 @@ def test_other_sampling_rates_end_to_end(tmp_path):
     random.seed(7)
     np.random.seed(7)
     bank = [_read_wav(p) for p in ds.noise_files]
+    rirs = [_read_wav(p) for p in ds.rir_files]
     want = []
     for r, sr in zip(recs, rates):
-        aug, sr2, trace = oa.augment(read(r).copy(), sr, cfg, random, bank, np_rnd=np.random, noise_rates=[22050, 22050])
+        aug, sr2, trace = oa.augment(read(r).copy(), sr, cfg, random, bank, np_rnd=np.random, noise_rates=[22050, 22050],
+                                     rir_bank=rirs, rir_rates=[16000, 16000])
+        assert [t[0] for t in trace][:3] == ["resample", "noise", "reverb"]
         want.append(rs.resample(aug, sr2, 16000) if sr2 != 16000 else aug)
     err = np.abs(got - ol.logmel_f32(want, n_mel=80)).reshape(len(recs), -1).max(axis=1)
     print("multi-rate augmented max-abs-err:", err)

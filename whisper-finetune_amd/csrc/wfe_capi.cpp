@@ -34,6 +34,7 @@ struct wfe_context {
   bool timing = false;
   std::vector<hipEvent_t> ev_pool;      // triples: before K1, after K1, after K2
   size_t ev_used = 0;
+  unsigned* d_peaks = nullptr;              // reverb: max|x|, max|y| per utterance of a slice
   double* d_partials = nullptr;             // resolve pass: per-part sums of the batch slice
   struct RsTable {
     float* d = nullptr;
@@ -300,6 +301,7 @@ int wfe_destroy(wfe_handle h) {
   for (auto& kv : h->rs_tables)
     if (kv.second.d) (void)hipFree(kv.second.d);
   if (h->d_partials) (void)hipFree(h->d_partials);
+  if (h->d_peaks) (void)hipFree(h->d_peaks);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   delete h;
   return WFE_OK;
@@ -408,6 +410,39 @@ int wfe_augment_waveform(wfe_handle h, const float* wav, const int64_t* offsets,
     HIP_TRY(h, wfe::launch_resolve(a, s.count, h->d_partials, stream));
     HIP_TRY(h, wfe::launch_waveform(a, s.count, out + (long long)s.begin * n_samples,
                                     out_lengths ? out_lengths + s.begin : nullptr, stream));
+  }
+  return WFE_OK;
+}
+
+int wfe_reverb(wfe_handle h, const float* wav, const int64_t* offsets, const int32_t* lengths, int64_t row_stride,
+               int32_t batch, const float* rir, const int64_t* rir_offsets, int32_t n_rir, const int32_t* rir_index,
+               float* out, int64_t out_stride, void* stream_) {
+  if (!h) return fail(nullptr, WFE_ERR_ARG, "null handle");
+  if (batch < 0) return fail(h, WFE_ERR_ARG, "batch %d < 0", batch);
+  if (out_stride < 1 || out_stride >= (1LL << 30)) return fail(h, WFE_ERR_ARG, "bad out_stride");
+  if (offsets == nullptr && row_stride < 0) return fail(h, WFE_ERR_ARG, "negative row_stride");
+  if (batch == 0) return WFE_OK;
+  if (!wav || !lengths || !out || !rir_index) return fail(h, WFE_ERR_ARG, "null device pointer");
+  if (n_rir < 0 || (n_rir > 0 && (!rir || !rir_offsets))) return fail(h, WFE_ERR_ARG, "n_rir without impulse responses");
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DeviceGuard guard(h->cfg.device);
+  if (!guard.ok) return fail(h, WFE_ERR_HIP, "hipSetDevice(%d) failed", h->cfg.device);
+  if (!h->d_peaks) HIP_TRY(h, hipMalloc(&h->d_peaks, sizeof(unsigned) * 2 * kMaxBatchPerLaunch));
+  for (const Slice& s : slices(batch)) {
+    wfe::ReverbArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.wav = offsets ? wav : wav + (long long)s.begin * row_stride;
+    a.offsets = offsets ? reinterpret_cast<const long long*>(offsets) + s.begin : nullptr;
+    a.lengths = lengths + s.begin;
+    a.row_stride = row_stride;
+    a.rir = rir;
+    a.rir_off = reinterpret_cast<const long long*>(rir_offsets);
+    a.rir_index = rir_index + s.begin;
+    a.out = out + (long long)s.begin * out_stride;
+    a.out_stride = out_stride;
+    a.peaks = h->d_peaks;
+    HIP_TRY(h, hipMemsetAsync(h->d_peaks, 0, sizeof(unsigned) * 2 * kMaxBatchPerLaunch, stream));
+    HIP_TRY(h, wfe::launch_reverb(a, s.count, stream));
   }
   return WFE_OK;
 }

@@ -79,4 +79,19 @@ struct ResampleArgs {
 };
 hipError_t launch_resample(const ResampleArgs& a, int batch, hipStream_t stream);
 
+// ---- reverberation (CustomDataset.add_reverb, utils/reader.py:342-348)
+struct ReverbArgs {
+  const float* wav;              // float32 utterances
+  const long long* offsets;      // optional
+  const int* lengths;
+  long long row_stride;
+  const float* rir;              // all impulse responses back to back
+  const long long* rir_off;      // (n_rir + 1) prefix offsets
+  const int* rir_index;          // per utterance; < 0: copied through unchanged
+  float* out;                    // (batch, out_stride), rows zero behind lengths[b]
+  long long out_stride;
+  unsigned* peaks;               // (batch x 2) max |x|, max |y| as float bits (non-negative floats order as uints)
+};
+hipError_t launch_reverb(const ReverbArgs& a, int batch, hipStream_t stream);
+
 }  // namespace wfe

@@ -1204,6 +1204,94 @@ __global__ __launch_bounds__(256) void resample_kernel(const ResampleArgs a) {
   }
 }
 
+// ------------------------------------------------------------- reverberation
+// scipy.signal.fftconvolve(sample, rir, mode='same') restated as the direct sum
+//   y[n] = sum_k rir[k] * x[n + (Lr - 1) / 2 - k],   n in [0, len),
+// float32 fmaf in tap order (the reference's float32 FFT agrees to ~1e-6 of max|y|),
+// then the peak normalisation y * (max|x| / max|y|) of reader.py:346-347 in a
+// second pass.  One workgroup = 2048 outputs of one utterance (thread t owns
+// n0 + t + 256 i): per chunk of 512 taps the taps and the input span they touch are
+// staged in LDS; lanes read consecutive addresses.
+constexpr int kRvOut = 2048, kRvTaps = 512;
+__global__ __launch_bounds__(256) void reverb_kernel(const ReverbArgs a) {
+  __shared__ float xs[kRvOut + kRvTaps];
+  __shared__ float hs[kRvTaps];
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const long long n0 = (long long)blockIdx.x * kRvOut;
+  if (n0 >= a.out_stride) return;
+  int len = a.lengths[b];
+  if (len < 0) len = 0;
+  if (len > a.out_stride) len = (int)a.out_stride;
+  float* __restrict__ o = a.out + (long long)b * a.out_stride;
+  long long n_end = n0 + kRvOut;
+  if (n_end > a.out_stride) n_end = a.out_stride;
+  if (n0 >= len) {
+    for (long long n = n0 + tid; n < n_end; n += 256) o[n] = 0.f;
+    return;
+  }
+  const float* __restrict__ x = a.wav + (a.offsets ? a.offsets[b] : (long long)b * a.row_stride);
+  const int ri = a.rir_index[b];
+  if (ri < 0) {                                        // no reverb for this utterance
+    for (long long n = n0 + tid; n < n_end; n += 256) o[n] = n < len ? x[n] : 0.f;
+    return;
+  }
+  const long long h0 = a.rir_off[ri];
+  const int lr = (int)(a.rir_off[ri + 1] - h0);
+  const int c = (lr - 1) / 2;
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  for (int k0 = 0; k0 < lr; k0 += kRvTaps) {
+    const int kc = (lr - k0 < kRvTaps) ? lr - k0 : kRvTaps;
+    // inputs touched by taps [k0, k0 + kc): s = n + c - k, n in [n0, n0 + 2048)
+    const long long s_lo = n0 + c - (k0 + kc - 1);
+    __syncthreads();
+    for (int i = tid; i < kRvOut + kc - 1; i += 256) {
+      const long long s2 = s_lo + i;
+      xs[i] = (s2 >= 0 && s2 < len) ? x[s2] : 0.f;
+    }
+    for (int i = tid; i < kc; i += 256) hs[i] = a.rir[h0 + k0 + i];
+    __syncthreads();
+    for (int kk = 0; kk < kc; ++kk) {
+      const float hv = hs[kk];
+      const int base = tid + (kc - 1 - kk);            // n0 + tid + c - (k0 + kk) - s_lo
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = fmaf(hv, xs[base + 256 * i], acc[i]);
+    }
+  }
+  float pk_y = 0.f, pk_x = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const long long n = n0 + tid + 256 * i;
+    if (n < n_end) {
+      const bool in = n < len;
+      o[n] = in ? acc[i] : 0.f;
+      if (in) {
+        pk_y = fmaxf(pk_y, fabsf(acc[i]));
+        pk_x = fmaxf(pk_x, fabsf(x[n]));
+      }
+    }
+  }
+  pk_y = wave_reduce<true>(pk_y);
+  pk_x = wave_reduce<true>(pk_x);
+  if ((tid & 63) == 0) {                               // NaN peaks (NaN input) are not propagated: max ignores them
+    atomicMax(a.peaks + 2 * b, __float_as_uint(pk_x));
+    atomicMax(a.peaks + 2 * b + 1, __float_as_uint(pk_y));
+  }
+}
+
+// sample_convolved * (max|sample| / max|sample_convolved|): float32 division, float32 product
+__global__ __launch_bounds__(256) void reverb_scale_kernel(const ReverbArgs a) {
+  const int b = blockIdx.y;
+  if (a.rir_index[b] < 0) return;
+  int len = a.lengths[b];
+  if (len > a.out_stride) len = (int)a.out_stride;
+  const float rate = __fdiv_rn(__uint_as_float(a.peaks[2 * b]), __uint_as_float(a.peaks[2 * b + 1]));
+  float* __restrict__ o = a.out + (long long)b * a.out_stride;
+  for (long long n = (long long)blockIdx.x * 256 + threadIdx.x; n < len; n += (long long)gridDim.x * 256)
+    o[n] = __fmul_rn(o[n], rate);
+}
+
 // ------------------------------------------------------------- launchers
 template <int NMT, bool POWER, bool AUG, int BANK>
 static hipError_t launch_k1(const FrontArgs& a, int batch, hipStream_t stream) {
@@ -1251,6 +1339,17 @@ hipError_t launch_resolve(const FrontArgs& a, int batch, double* partials, hipSt
 hipError_t launch_waveform(const FrontArgs& a, int batch, float* out, int* out_lengths, hipStream_t stream) {
   const int gx = (a.n_samples + kBlockFrames * kHop - 1) / (kBlockFrames * kHop);
   hipLaunchKernelGGL(waveform_kernel, dim3(gx < 1 ? 1 : gx, batch), dim3(256), 0, stream, a, out, out_lengths);
+  return hipGetLastError();
+}
+
+hipError_t launch_reverb(const ReverbArgs& a, int batch, hipStream_t stream) {
+  const long long gx = (a.out_stride + kRvOut - 1) / kRvOut;
+  hipLaunchKernelGGL(reverb_kernel, dim3((unsigned)(gx < 1 ? 1 : gx), batch), dim3(256), 0, stream, a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  long long sx = (a.out_stride + 256 * 8 - 1) / (256 * 8);
+  if (sx > 256) sx = 256;
+  hipLaunchKernelGGL(reverb_scale_kernel, dim3((unsigned)(sx < 1 ? 1 : sx), batch), dim3(256), 0, stream, a);
   return hipGetLastError();
 }
 

@@ -44,6 +44,7 @@ SYMBOLS = {
                                      _P, _P, C.c_int32, _P, _P]),
     "wfe_logmel_pcm16": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int64,
                                    _P, _P, C.c_int32, _P, _P]),
+    "wfe_reverb": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, _P, _P, C.c_int32, _P, _P, C.c_int64, _P]),
     "wfe_resample": (C.c_int, [_P, _P, C.c_int32, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64,
                                _P, _P]),
     "wfe_resample_geometry": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P]),

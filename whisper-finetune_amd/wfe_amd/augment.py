@@ -20,8 +20,9 @@ Draw order restated from the reference:
             new rate).  A host-only marker op (HOST_RESAMPLE, rate) splits the chain into STAGES
             (``split_stages``): each stage is a fused chain at one rate, stages are joined by the
             GPU resampler (include/wfe.h wfe_resample), the last one ends at the target rate;
-  * reverb: gate drawn; firing raises NotImplementedError (not part of the
-            GPU chain yet) -- with the shipped config (placeholder rir_dir) it cannot fire.
+  * reverb: only when impulse responses exist: ``random.choice(rir_files)``; a host-only marker op
+            (HOST_REVERB, index) ends a stage like a resample does: the stage's waveform goes
+            through the GPU convolution (include/wfe.h wfe_reverb) at the current rate.
 """
 from __future__ import annotations
 
@@ -34,6 +35,7 @@ from ._lib import AUG_NOISE, AUG_SHIFT, AUG_SPEED, AUG_VOLUME
 
 Op = Tuple[int, int, int, int, float]      # (kind, i0, i1, i2, f0) -- see wfe_aug_op
 HOST_RESAMPLE = 100                        # (HOST_RESAMPLE, new_rate, 0, 0, 0.0): never sent to the device
+HOST_REVERB = 101                          # (HOST_REVERB, rir index, 0, 0, 0.0): likewise
 
 
 def resampled_length(n: int, orig_sr: int, target_sr: int) -> int:
@@ -42,25 +44,33 @@ def resampled_length(n: int, orig_sr: int, target_sr: int) -> int:
 
 
 def split_stages(ops: Sequence[Op], length: int, sample_rate: int, target_rate: int):
-    """-> [{"sr", "ops", "len_in", "len_out", "next_sr"}]: ``ops`` (device ops only) run on
-    ``len_in`` samples at ``sr`` and leave ``len_out``; the result is resampled to
-    ``next_sr`` (None after the last stage, which is always at ``target_rate``:
-    reader.py:157-158)."""
+    """-> [{"sr", "ops", "len_in", "len_out", "post"}]: ``ops`` (device ops only) run on
+    ``len_in`` samples at ``sr`` and leave ``len_out``; ``post`` is what joins the stage
+    to the next one: ("resample", new_sr), ("reverb", rir index) or None after the last
+    stage, which is always at ``target_rate`` (reader.py:157-158)."""
     stages, cur, sr, n = [], [], int(sample_rate), int(length)
     n_in = n
     for op in list(ops) + [(HOST_RESAMPLE, int(target_rate), 0, 0, 0.0)]:
         if op[0] == HOST_RESAMPLE:
             new_sr = int(op[1])
             if new_sr != sr:
-                stages.append({"sr": sr, "ops": cur, "len_in": n_in, "len_out": n, "next_sr": new_sr})
+                stages.append({"sr": sr, "ops": cur, "len_in": n_in, "len_out": n, "post": ("resample", new_sr)})
                 n = resampled_length(n, sr, new_sr)
                 cur, sr, n_in = [], new_sr, n
+            continue
+        if op[0] == HOST_REVERB:
+            stages.append({"sr": sr, "ops": cur, "len_in": n_in, "len_out": n, "post": ("reverb", int(op[1]))})
+            cur, n_in = [], n
             continue
         if op[0] == AUG_SPEED:
             n = int(op[1])
         cur.append(op)
-    stages.append({"sr": sr, "ops": cur, "len_in": n_in, "len_out": n, "next_sr": None})
+    stages.append({"sr": sr, "ops": cur, "len_in": n_in, "len_out": n, "post": None})
     return stages
+
+
+def is_host_op(op: Op) -> bool:
+    return op[0] in (HOST_RESAMPLE, HOST_REVERB)
 
 
 class AugmentPlanner:
@@ -123,6 +133,5 @@ class AugmentPlanner:
                     ops.append((AUG_NOISE, j, start, snr, 0.0))
             if kind == "reverb" and rnd.random() < prob:
                 if self.n_rir_files > 0:
-                    rnd.choice(range(self.n_rir_files))
-                    raise NotImplementedError("reverb augmentation is not part of the GPU chain yet (SURVEY 8f N1)")
+                    ops.append((HOST_REVERB, rnd.choice(range(self.n_rir_files)), 0, 0, 0.0))
         return ops, n

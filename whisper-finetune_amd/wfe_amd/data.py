@@ -35,7 +35,7 @@ from typing import Any, List, Optional
 import numpy as np
 import torch
 
-from .augment import HOST_RESAMPLE, AugmentPlanner, split_stages
+from .augment import AugmentPlanner, is_host_op, split_stages
 
 try:                                    # audio decode is host I/O, outside the GPU path
     import soundfile as _sf
@@ -253,6 +253,8 @@ class CustomDataset(torch.utils.data.Dataset):
         self.rir_files: Optional[List[str]] = None
         self.noise_clips: List[np.ndarray] = []     # decoded once, uploaded by the collator
         self.noise_rates: List[int] = []            # their native sampling rates
+        self.rir_clips: List[np.ndarray] = []       # impulse responses, likewise
+        self.rir_rates: List[int] = []
         self.planner: Optional[AugmentPlanner] = None
         if augment_config_path:
             with open(augment_config_path, "r", encoding="utf-8") as f:
@@ -284,10 +286,18 @@ class CustomDataset(torch.utils.data.Dataset):
                     clip = clip.mean(axis=0)
                 self.noise_clips.append(np.ascontiguousarray(clip, dtype=np.float32))
                 self.noise_rates.append(int(sr))     # resampled on the GPU to whatever rate an utterance has (reader.py:323)
+            for p in self.rir_files or []:           # reader.py:343 librosa.load(rir_file, ...): mono float32
+                clip, sr = read_audio(p)
+                clip = clip.T
+                if clip.ndim > 1:
+                    clip = clip.mean(axis=0)
+                self.rir_clips.append(np.ascontiguousarray(clip, dtype=np.float32))
+                self.rir_rates.append(int(sr))
             self.planner = AugmentPlanner(self.augment_configs, [len(c) for c in self.noise_clips],
                                           len(self.rir_files or []), noise_rates=self.noise_rates)
-            if self.noise_clips:
-                _NOISE_CLIPS[id(processor)] = (self.noise_clips, self.noise_rates)
+            if self.noise_clips or self.rir_clips:
+                _NOISE_CLIPS[id(processor)] = {"noise": (self.noise_clips, self.noise_rates),
+                                               "rir": (self.rir_clips, self.rir_rates)}
 
     @staticmethod
     def _load_wav_files(data_dir):
@@ -474,23 +484,25 @@ class DataCollatorSpeechSeq2SeqWithPadding:
         self.device = device
         self.device_output = (os.environ.get("WFE_DEVICE_OUTPUT", "0") == "1") if device_output is None \
             else bool(device_output)
-        self._noise_src = (noise_clips, noise_rates) if noise_clips is not None else None
+        self._clip_src = {"noise": (noise_clips, noise_rates)} if noise_clips is not None else None
         self._noise_banks: dict = {}
         self._packer = None
 
-    def set_noise_clips(self, clips, rates=None):
-        """The decoded noise clips of ``CustomDataset.noise_clips`` and their native
-        rates (uploaded once; resampled on the GPU per utterance rate on first use)."""
-        self._noise_src, self._noise_banks = (clips, rates), {}
+    def set_noise_clips(self, clips, rates=None, rir_clips=None, rir_rates=None):
+        """The decoded noise clips (and impulse responses) of ``CustomDataset`` with their
+        native rates (uploaded once; resampled on the GPU per utterance rate on first use)."""
+        self._clip_src = {"noise": (clips, rates), "rir": (rir_clips or [], rir_rates)}
+        self._noise_banks = {}
 
-    def _bank(self, fe, rate: int):
-        """Noise clips at ``rate``: what ``librosa.load(noise_path, sr=rate)`` hands
-        add_noise (reader.py:323), resident on the device."""
+    def _bank(self, fe, rate: int, kind: str = "noise"):
+        """Noise clips / impulse responses at ``rate``: what ``librosa.load(path, sr=rate)``
+        hands add_noise / add_reverb (reader.py:323,343), resident on the device."""
         from .frontend import NoiseBank
         rate = int(rate)
-        if rate in self._noise_banks:
-            return self._noise_banks[rate]
-        src = self._noise_src if self._noise_src is not None else _NOISE_CLIPS.get(id(self.processor))
+        if (kind, rate) in self._noise_banks:
+            return self._noise_banks[(kind, rate)]
+        srcs = self._clip_src if self._clip_src is not None else _NOISE_CLIPS.get(id(self.processor))
+        src = (srcs or {}).get(kind)
         bank = None
         if src and src[0]:
             clips, rates = src
@@ -506,7 +518,7 @@ class DataCollatorSpeechSeq2SeqWithPadding:
                         t = o[0, :fe.resampled_length(len(c), int(r), rate)]
                     on_dev.append(t)
                 bank = NoiseBank.from_tensors(on_dev, fe.device)
-        self._noise_banks[rate] = bank
+        self._noise_banks[(kind, rate)] = bank
         return bank
 
     def _staged(self, fe, group: List[dict], stages: List[list], n_samples: int) -> torch.Tensor:
@@ -514,18 +526,22 @@ class DataCollatorSpeechSeq2SeqWithPadding:
         at the target rate, or a resample augmentation): every stage but the last is
         [fused chain -> waveform] -> GPU resampler, the last is the fused
         chain + log-mel launch at the target rate."""
-        first_has_ops = any(st[0]["ops"] for st in stages)
-        wav, off, lens, ch = self._packer.pack([it["waveform"] for it in group], force_float=first_has_ops)
+        need_float = any(st[0]["ops"] for st in stages) or stages[0][0]["post"][0] == "reverb"
+        wav, off, lens, ch = self._packer.pack([it["waveform"] for it in group], force_float=need_float)
         n_stage = len(stages[0])
         for k in range(n_stage - 1):
-            sr, nxt = stages[0][k]["sr"], stages[0][k]["next_sr"]
+            sr, post = stages[0][k]["sr"], stages[0][k]["post"]
             plans = [st[k]["ops"] for st in stages]
             host_lens = [st[k]["len_out"] for st in stages]
             if any(plans):
                 width = (max(max(host_lens), 1) + 3) // 4 * 4
                 wav, lens = fe.augment_waveform(wav, lens, plans, self._bank(fe, sr), n_samples=width, offsets=off)
                 off, ch = None, 1
-            wav, lens = fe.resample(wav, lens, sr, nxt, offsets=off, channels=ch, host_lengths=host_lens)
+            if post[0] == "resample":
+                wav, lens = fe.resample(wav, lens, sr, post[1], offsets=off, channels=ch, host_lengths=host_lens)
+            else:                                          # reverb: same rate, same lengths
+                wav = fe.reverb(wav, lens, self._bank(fe, sr, "rir"), [st[k]["post"][1] for st in stages],
+                                offsets=off, host_lengths=host_lens)
             off, ch = None, 1
         plans = [st[-1]["ops"] for st in stages]
         if any(plans):
@@ -554,11 +570,13 @@ class DataCollatorSpeechSeq2SeqWithPadding:
             for j, i in enumerate(gpu_items):
                 it = items[i]
                 ops, sr = it.get("aug_ops") or [], int(it.get("sample_rate", target))
-                if sr == int(it.get("target_rate", target)) and not any(op[0] == HOST_RESAMPLE for op in ops):
+                if sr == int(it.get("target_rate", target)) and not any(is_host_op(op) for op in ops):
                     simple.append(j)
                 else:
                     st = split_stages(ops, it["waveform"].shape[0], sr, int(it.get("target_rate", target)))
-                    staged.setdefault(tuple(s["sr"] for s in st), []).append((j, st))
+                    sig = tuple((s["sr"], s["post"][0] if s["post"] else None,
+                                 s["post"][1] if s["post"] and s["post"][0] == "resample" else None) for s in st)
+                    staged.setdefault(sig, []).append((j, st))
             out = None
             if simple:
                 sel = [items[gpu_items[j]] for j in simple]

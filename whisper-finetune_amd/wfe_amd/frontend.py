@@ -181,6 +181,33 @@ class HipFrontEnd:
             batch, int(orig_sr), int(target_sr), _ptr(out), int(out_stride), _ptr(out_lengths), self._stream()), self._h)
         return out, out_lengths
 
+    # ------------------------------------------------------------ reverberation
+    def reverb(self, wav: torch.Tensor, lengths: torch.Tensor, rirs: "NoiseBank", rir_index: Sequence[int],
+               offsets: Optional[torch.Tensor] = None, out_stride: Optional[int] = None,
+               host_lengths: Optional[Sequence[int]] = None) -> torch.Tensor:
+        """CustomDataset.add_reverb (reader.py:342-348) for a batch of float32 utterances:
+        (B, out_stride) float32, rows zero behind their length (lengths do not change).
+        ``rirs``: impulse responses on the device (a NoiseBank); ``rir_index[b] < 0``
+        copies utterance b through."""
+        batch, stride = self._geometry(wav, lengths, offsets)
+        self._check_inputs(wav, lengths, offsets, batch)
+        if wav.dtype != torch.float32:
+            raise ValueError("reverb takes float32 utterances")
+        if len(rir_index) != batch:
+            raise ValueError("one impulse-response index per utterance")
+        if any(int(i) >= rirs.n for i in rir_index):
+            raise ValueError("impulse-response index out of range")
+        if out_stride is None:
+            if host_lengths is None:
+                host_lengths = lengths.cpu().tolist()
+            out_stride = (max(max(host_lengths, default=1), 1) + 3) // 4 * 4
+        out = torch.empty((batch, int(out_stride)), dtype=torch.float32, device=self.device)
+        idx = torch.tensor([int(i) for i in rir_index], dtype=torch.int32).to(self.device)
+        _lib.check(_lib.lib().wfe_reverb(self._h, _ptr(wav), _ptr(offsets), _ptr(lengths), stride, batch,
+                                         _ptr(rirs.data), _ptr(rirs.offsets), rirs.n, _ptr(idx), _ptr(out),
+                                         int(out_stride), self._stream()), self._h)
+        return out
+
     # ------------------------------------------------------------ augmentation
     _OP_DTYPE = np.dtype([("kind", "<i4"), ("i0", "<i4"), ("i1", "<i4"), ("i2", "<i4"),
                           ("f0", "<f4"), ("f1", "<f4"), ("d0", "<f8")])     # == wfe_aug_op, 32 bytes
