@@ -274,11 +274,14 @@ def main() -> None:
         clips = args.batch * args.steps * world
         k1_avg_s = k1_ms / max(launches, 1) / 1e3
         achieved = ALGO_GFLOP[args.n_mel] * args.batch / k1_avg_s / 1e3          # TFLOP/s
-        traffic, traffic_src = None, None
+        traffic, traffic_src, clamp_gbs = None, None, None
         try:   # HBM bytes per launch measured offline with rocprofv3 PMC passes (same batch / n_mel only)
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             if tj["batch"] == args.batch and tj["n_mel"] == args.n_mel:
                 traffic = (tj["frontend_kernel"]["fetch_bytes"] + tj["frontend_kernel"]["write_bytes"]) / 1e9
+                if not args.augment and args.lengths == "full" and k2_ms > 0:      # data-dependent: same clips only
+                    ck = tj["clamp_kernel"]
+                    clamp_gbs = (ck["fetch_bytes"] + ck["write_bytes"]) / (k2_ms / max(launches, 1) / 1e3) / 1e9
                 traffic_src = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, GB per launch; " \
                               "algorithmic %.3f GB)" % (ALGO_BYTES[args.n_mel] * args.batch / 1e9)
         except Exception:  # noqa: BLE001
@@ -314,6 +317,8 @@ def main() -> None:
                 "executed_mfma_tflops": 47 * 4 * (700 + (72 if args.n_mel <= 80 else 84)) * 2048 * args.batch
                 / k1_avg_s / 1e12,
                 "clamp_kernel_ms_avg": k2_ms / max(launches, 1),
+                # the elementwise stage against HBM: measured bytes (profiles/traffic.json) / measured time
+                "clamp_kernel_hbm_gbs": clamp_gbs, "clamp_kernel_hbm_frac": clamp_gbs / PEAK_HBM_GBS if clamp_gbs else None,
                 "hbm_algorithmic_gbs": ALGO_BYTES[args.n_mel] * args.batch / k1_avg_s / 1e9,
             },
             "checksum": checksum,
