@@ -63,22 +63,21 @@ for k in np.unique(key)[:200]:
 print("fraction of k-loop time overlapped by another k-loop on the same SIMD: %.3f" % (ov / max(tot_k, 1)))
 
 # residency: how long each SIMD holds 0 / 1 / 2 waves of this kernel (stamp 0 .. stamp 5 of a
-# wave; the time between one workgroup's end and its successor's start shows up as "1 resident")
-t_begin, t_end = s[:, 0].min(), s[:, 5].max()
+# wave; the time between one workgroup's end and its successor's start shows up as "1 resident").
+# Each XCD has its own clock base, so every SIMD is measured against its own first / last stamp.
 level_time = np.zeros(4)
 gaps = []
 for k in np.unique(key)[:400]:
     w = s[key == k]
     ev = sorted([(t, 1) for t in w[:, 0]] + [(t, -1) for t in w[:, 5]])
-    lvl, last = 0, t_begin
+    lvl, last = 0, ev[0][0]
     for t, dlt in ev:
         level_time[min(lvl, 3)] += t - last
         lvl, last = lvl + dlt, t
-    level_time[min(lvl, 3)] += t_end - last
     ends = np.sort(w[:, 5])
     starts = np.sort(w[:, 0])[2:]                       # the first two start at launch
     if len(starts):
         gaps.append(np.median(starts - ends[:len(starts)]))
 level_time /= level_time.sum()
-print("SIMD residency: 0 waves %.3f, 1 wave %.3f, 2 waves %.3f" % tuple(level_time[:3]))
+print("SIMD residency between its first and last stamp: 0 waves %.3f, 1 wave %.3f, 2 waves %.3f" % tuple(level_time[:3]))
 print("median (successor start - predecessor end) per SIMD slot: %.0f cycles" % np.median(gaps))
