@@ -503,7 +503,10 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   // non-MFMA phase so that its k-loop runs under its neighbour's staging and
   // epilogue from then on.  The CU is identified from HW_ID / XCC_ID; a wrong
   // guess only costs the overlap.
-  if (STAGGER) {
+  // (It costs a global atomic round trip, so interior tiles call it with their
+  // waveform loads already in flight.)
+  auto stagger = [&]() {
+    if (!STAGGER) return;
     if (tid == 0) {
       const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID
       const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);      // HW_REG_XCC_ID[3:0]
@@ -527,7 +530,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
       __builtin_amdgcn_s_sleep(127);
       __builtin_amdgcn_s_sleep(127);
     }
-  }
+  };
 
   // k-steps 0 and 1 of the twiddle table (8 KB each): in flight while the
   // waveform is staged, then parked in the two LDS slots
@@ -545,6 +548,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
     const bool interior16 = inside && src.pcm && src.ch == 1 &&
                             ((reinterpret_cast<uintptr_t>(src.pcm + i_first) & 15u) == 0);
     if (AUG) {
+      stagger();
       stage_augmented<kAuxFloats>(c, lds, lds + kLdsWaveFloats, p0, n, len, tid);
     } else if (interior16) {
       // 16-bit PCM: 8 samples per 16-byte load, converted on the way into LDS
@@ -558,6 +562,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
         const int v8 = tid + 256 * it;
         if (v8 < kVec) buf[it] = src8[v8];
       }
+      stagger();
       constexpr float kScale = 1.0f / 32768.0f;
 #pragma unroll
       for (int it = 0; it < kIters; ++it) {
@@ -583,6 +588,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
         const int v4 = tid + 256 * it;
         if (v4 < kBlockSamples / 4) buf[it] = src[v4];
       }
+      stagger();
 #pragma unroll
       for (int it = 0; it < kIters; ++it) {
         const int v4 = tid + 256 * it;
@@ -596,6 +602,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
         }
       }
     } else {
+      stagger();
       constexpr int kBatch = 7;                 // 41 positions per thread in 6 batches of 7
       for (int q0 = tid; q0 < kBlockSamples; q0 += 256 * kBatch) {
         float vals[kBatch];
