@@ -50,6 +50,8 @@ xcc = s[:, 6] >> 32
 key = (xcc << 16) | (((hw >> 8) & 255) << 4) | ((hw >> 4) & 3)
 print("distinct (xcc,cu,simd):", len(np.unique(key)), " distinct (xcc,cu):", len(np.unique(key >> 4)),
      )
+if len(np.unique(key)) < 8:          # stamps 6 / 7 not written by this kernel variant: no per-SIMD analysis
+    sys.exit(0)
 ov, tot_k = 0, 0
 for k in np.unique(key)[:200]:
     w = s[key == k]

@@ -5,6 +5,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <new>
@@ -41,6 +42,7 @@ struct wfe_context {
     int L = 0, M = 0, taps = 0, k0 = 0;
   };
   std::map<std::pair<int, int>, RsTable> rs_tables;   // (in_rate, out_rate) -> filter on the device
+  int k1_variant = 4;                       // WFE_K1=4 | 8 | 2 selects the kernel-1 variant (A/B runs; 4 is the fastest)
   float* d_block_min = nullptr;             // per-wave minima of kernel 1, grows on demand
   size_t block_min_cap = 0;
   unsigned long long* d_stamps = nullptr;   // diagnostic builds only (wfe_debug_stamps)
@@ -181,7 +183,7 @@ int run_frontend(wfe_context* h, const void* wav, int channels, const int64_t* o
   const int T = n_samples / wfe::kHop;
   if (mode == 0) {
     const size_t per_slice = (size_t)(batch < kMaxBatchPerLaunch ? batch : kMaxBatchPerLaunch) *
-                             ((T + wfe::kBlockFrames - 1) / wfe::kBlockFrames) * 4;
+                             ((T + wfe::kBlockFrames - 1) / wfe::kBlockFrames) * 8;
     if (per_slice > h->block_min_cap) {
       if (h->d_block_min) HIP_TRY(h, hipFree(h->d_block_min));
       h->d_block_min = nullptr;
@@ -225,7 +227,7 @@ int run_frontend(wfe_context* h, const void* wav, int channels, const int64_t* o
       h->ev_used += 3;
       HIP_TRY(h, hipEventRecord(ev[0], stream));
     }
-    HIP_TRY(h, wfe::launch_frontend(a, s.count, mode, aug, h->bank, stream));
+    HIP_TRY(h, wfe::launch_frontend(a, s.count, mode, aug, h->bank, stream, h->k1_variant));
     if (ev) HIP_TRY(h, hipEventRecord(ev[1], stream));
     if (mode == 0)
       HIP_TRY(h, wfe::launch_clamp(a.out, h->d_clip_max, h->d_block_min, s.count, h->cfg.n_mel, T, stream));
@@ -272,6 +274,7 @@ int wfe_create(const wfe_config* cfg, wfe_handle* out) {
   wfe_build_mel_table(cfg->n_mel, mel.data(), h->mel_mask);
   if (cfg->n_mel == 80 && std::memcmp(h->mel_mask, wfe::kMelMask80, sizeof h->mel_mask) == 0) h->bank = 1;
   if (cfg->n_mel == 128 && std::memcmp(h->mel_mask, wfe::kMelMask128, sizeof h->mel_mask) == 0) h->bank = 2;
+  if (const char* k1 = std::getenv("WFE_K1")) h->k1_variant = std::atoi(k1);
 
   DeviceGuard guard(cfg->device);
   hipError_t e = guard.ok ? hipSuccess : hipErrorInvalidDevice;

@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
         // clamp, so kernel 2 (which knows the utterance maximum) writes its final value
         // once.  -inf marks the tile as silent; real minima are >= -10.
         if (tid == 0) atomicMax(a.clip_max + b, enc_max(-10.0f));
-        if (tid < 4) a.block_min[((long long)b * nblk + blockIdx.x) * 4 + tid] = -INFINITY;
+        if (tid < 8) a.block_min[((long long)b * nblk + blockIdx.x) * 8 + tid] = -INFINITY;
       }
       return;
     }
@@ -872,7 +872,8 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
 #endif
   if (lane == 0) {
     if (wmax > -INFINITY) atomicMax(a.clip_max + b, enc_max(wmax));
-    a.block_min[((long long)b * nblk + blockIdx.x) * 4 + wave] = wmin;
+    a.block_min[((long long)b * nblk + blockIdx.x) * 8 + 2 * wave] = wmin;      // both halves of the
+    a.block_min[((long long)b * nblk + blockIdx.x) * 8 + 2 * wave + 1] = wmin;  // frame group's pair
   }
 #if defined(WFE_STAMPS) && WFE_STAMPS == 2
   WFE_STAMP(6);
@@ -907,6 +908,414 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   WFE_STAMP(5);
 }
 
+// ------------------------------------------------ kernel 1, 8-wave variant
+// Same transform, same tables, same LDS waveform image, but the 64 frames of a
+// workgroup are worked by EIGHT waves: wave = (frame group fg = wave & 3, parity
+// class cls = wave >> 2).  A wave runs only the two GEMMs of its class (cos and sin
+// sums over the even-n or the odd-n half of the folded samples): 14 accumulators
+// instead of 28, under 128 VGPRs, so FOUR waves are resident per SIMD instead of
+// two.  That is what the 4-wave kernel lacks: a wave's serial non-MFMA time
+// (staging latency, mel weights, epilogue, workgroup turnover: ~36k cycles against
+// 24.7k cycles of MFMA) cannot be covered by ONE partner wave per SIMD; three can.
+// The butterflies need both classes, so after the k-loop the two waves of a frame
+// group swap halves through LDS (class 0 keeps bin tiles 0-3, class 1 tiles 4-6),
+// each does power + a partial mel projection for its tiles, and class 1 hands its
+// partial mel sums of the mel tiles the other one finishes.  EXPERIMENTAL (WFE_K1=8 or 2):
+// correct and tested, but measured 2-9 % SLOWER than frontend_kernel, which
+// stays the default; exists for the two Whisper banks without augmentation / power output.
+#define WFE_STAMP8(i)                                                                   \
+  do {                                                                                  \
+    if (WFE_STAMPS_ON && a.stamps && lane == 0 && cls == 0) {                           \
+      unsigned long long t_;                                                            \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
+      a.stamps[((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + (t0 >> 6)) * 4 + ((t0 & 63) >> 4) + fg) * 8 + (i)] = t_; \
+    }                                                                                   \
+  } while (0)
+#ifdef WFE_STAMPS
+constexpr bool WFE_STAMPS_ON = true;
+#else
+constexpr bool WFE_STAMPS_ON = false;
+#endif
+
+// FG = frame groups (of 16 frames) per workgroup: the workgroup has 2 FG waves and
+// covers 16 FG frames.  FG = 2 (4 waves, 32 frames, 38 KB of LDS) puts FOUR
+// workgroups on a CU, one wave of each on every SIMD: four independent phase
+// streams per SIMD (waves of one workgroup are phase-locked by its barriers, so
+// FG = 4 -- two workgroups of 8 waves -- has only two).
+template <int NMT, int BANK, int FG>
+__global__ __launch_bounds__(128 * FG, 4) void frontend8_kernel(const FrontArgs a) {
+  static_assert(BANK == 1 || BANK == 2, "compile-time mel masks only");
+  static_assert(FG == 2 || FG == 4, "2 or 4 frame groups");
+  constexpr int NT = 128 * FG;                                     // threads
+  constexpr int BF = 16 * FG;                                      // frames per workgroup
+  constexpr int BS = BF * kHop + (kNfft - kHop);                   // padded-signal positions they cover
+  constexpr int kWave = (BS + BS / kHop + 4) / 4 * 4;              // LDS image: position q at q + q / 160
+  constexpr int TW = 512 / NT;                                     // twiddle float4 per thread and k-step
+  constexpr int kXFloats = FG * 3584;                              // class exchange
+  constexpr int kYFloats = FG * NMT * 256;                         // partial mel sums of class 1
+  constexpr int kLoop = kWave + 2 * kDftStepFloats;                // waveform image + 2 twiddle slots
+  // Y behind X when that still leaves 4 (FG = 2) / 2 (FG = 4) workgroups per CU: saves a barrier
+  constexpr bool kYSeparate = kXFloats + kYFloats <= (FG == 2 ? 9984 : 20224);
+  constexpr int kPost = kYSeparate ? kXFloats + kYFloats : (kXFloats > kYFloats ? kXFloats : kYFloats);
+  constexpr int kLds = kLoop > kPost ? kLoop : kPost;
+  constexpr int kOwn0 = (NMT + 1) / 2;                             // mel tiles finished by class 0; class 1: the rest
+  __shared__ __attribute__((aligned(16))) float lds[kLds];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fg = wave & (FG - 1), cls = wave / FG;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * BF;
+  const int n = a.n_samples;
+  const int T = a.n_frames;
+  const int nblk = (T + kBlockFrames - 1) / kBlockFrames;
+  const Source src = make_source(a, b);
+  const float* __restrict__ w = src.w;
+  int len = a.lengths[b];
+  if (len < 0) len = 0;
+  if (len > n) len = n;                         // truncation=True (HF:300-307)
+  WFE_STAMP8(0);
+  const int p0 = t0 * kHop;
+  const int i_first = p0 - kHalf;
+  {                                             // silent workgroup: see frontend_kernel
+    const int i_last = i_first + BS - 1;
+    if (i_first >= len && (i_last < n || 2 * (n - 1) - i_last >= len)) {
+      if (tid == 0) atomicMax(a.clip_max + b, enc_max(-10.0f));
+      if (tid < 2 * FG) a.block_min[(((long long)b * nblk + (t0 >> 6)) * 4 + ((t0 & 63) >> 4)) * 2 + tid] = -INFINITY;
+      return;
+    }
+  }
+  auto stagger = [&]() {                        // see frontend_kernel
+    if (tid == 0) {
+      const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+      const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+      const unsigned key = ((xcc & 15u) << 8) | ((hw >> 8) & 255u);
+      lds[0] = __uint_as_float(atomicAdd(a.cu_tickets + key, 1u));
+    }
+    __syncthreads();
+    const unsigned ticket = __float_as_uint(lds[0]);
+    __syncthreads();
+    // the workgroups that start together on a CU (2 or 4) are spread over one lifetime
+    const unsigned first_round = 8 / FG;
+    if (ticket > 0u && ticket < first_round)
+      for (unsigned i = 0; i < ticket * (FG == 2 ? 2u : 3u); ++i) __builtin_amdgcn_s_sleep(127);
+  };
+
+  // twiddles of k-steps 0, 1 (-> the two LDS slots) and 2 (staging register): one float4 per thread and step
+  const f32x4* __restrict__ gtab = reinterpret_cast<const f32x4*>(a.dft_tab) + tid;
+  f32x4* const slots = reinterpret_cast<f32x4*>(lds + kWave);                // 2 x 512 float4
+  // Three staging sets: the twiddles of step s+4 are requested in step s and parked in
+  // LDS in step s+2 -- two whole steps for the L2 round trip (a step of this kernel is
+  // short: 14 MFMAs).  Set s % 3 receives in step s, set (s + 1) % 3 is written out.
+  f32x4 g0[TW], g1[TW], G[3][TW];
+#pragma unroll
+  for (int i = 0; i < TW; ++i) {
+    g0[i] = gtab[NT * i];
+    g1[i] = gtab[512 + NT * i];
+    G[1][i] = gtab[1024 + NT * i];          // A(2), written out in step 0
+    G[2][i] = gtab[1536 + NT * i];          // A(3), written out in step 1
+    G[0][i] = G[1][i];
+  }
+
+  // ---- stage the padded-signal span [160 t0, 160 t0 + 10480) into LDS
+  {
+    const bool inside = i_first >= 0 && i_first + BS <= len;
+    const bool interior = inside && w && ((reinterpret_cast<uintptr_t>(w + i_first) & 15u) == 0);
+    const bool interior16 = inside && src.pcm && src.ch == 1 &&
+                            ((reinterpret_cast<uintptr_t>(src.pcm + i_first) & 15u) == 0);
+    if (interior16) {
+      using i32x4 = __attribute__((ext_vector_type(4))) int;
+      const i32x4* __restrict__ src8 = reinterpret_cast<const i32x4*>(src.pcm + i_first);
+      constexpr int kVec = BS / 8;
+      constexpr int kIters = (kVec + NT - 1) / NT;
+      i32x4 buf[kIters];
+#pragma unroll
+      for (int it = 0; it < kIters; ++it) {
+        const int v8 = tid + NT * it;
+        if (v8 < kVec) buf[it] = src8[v8];
+      }
+      stagger();
+      constexpr float kScale = 1.0f / 32768.0f;
+#pragma unroll
+      for (int it = 0; it < kIters; ++it) {
+        const int v8 = tid + NT * it;
+        if (v8 < kVec) {
+          const int q = 8 * v8;
+          const int base = q + q / kHop;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int pair = buf[it][j];
+            lds[base + 2 * j + 0] = (float)(short)(pair & 0xffff) * kScale;
+            lds[base + 2 * j + 1] = (float)(pair >> 16) * kScale;
+          }
+        }
+      }
+    } else if (interior) {
+      const f32x4* __restrict__ src4 = reinterpret_cast<const f32x4*>(w + i_first);
+      constexpr int kIters = (BS / 4 + NT - 1) / NT;
+      f32x4 buf[kIters];
+#pragma unroll
+      for (int it = 0; it < kIters; ++it) {
+        const int v4 = tid + NT * it;
+        if (v4 < BS / 4) buf[it] = (WFE_EXP & 256) ? f32x4{0.1f, 0.2f, -0.1f, 0.3f} : src4[v4];
+      }
+      stagger();
+#pragma unroll
+      for (int it = 0; it < kIters; ++it) {
+        const int v4 = tid + NT * it;
+        if (v4 < BS / 4) {
+          const int q = 4 * v4;
+          const int base = q + q / kHop;
+          lds[base + 0] = buf[it][0];
+          lds[base + 1] = buf[it][1];
+          lds[base + 2] = buf[it][2];
+          lds[base + 3] = buf[it][3];
+        }
+      }
+    } else {
+      stagger();
+      constexpr int kBatch = 7;
+      for (int q0 = tid; q0 < BS; q0 += NT * kBatch) {
+        float vals[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+          const int q = q0 + NT * u;
+          int i = p0 + q - kHalf;
+          if (i < 0) i = -i;                    // reflect
+          if (i >= n) i = 2 * (n - 1) - i;
+          float v = 0.f;
+          if (q < BS && i >= 0 && i < len) v = src.at(i);
+          vals[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+          const int q = q0 + NT * u;
+          if (q < BS) lds[pad_q(q)] = vals[u];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TW; ++i) {
+    slots[NT * i + tid] = g0[i];
+    slots[512 + NT * i + tid] = g1[i];
+  }
+  WFE_STAMP8(1);
+  __syncthreads();
+  WFE_STAMP8(2);
+
+  // ---- this wave's two GEMMs (cos . e and sin . o over its parity class)
+  const int jl = lane & 15;
+  const int kk = lane >> 4;
+  const int d_lo = 2 * (kk >> 1) + 16 * (kk & 1);
+  const int d_hi = 2 * kk;
+  const int rowbase = 161 * (fg * 16 + jl);
+  const int c0 = cls ? 1 : 2;
+  f32x4 acc[2][7];
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int bt = 0; bt < 7; ++bt) acc[g][bt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float xf = 0.f, xb = 0.f;
+  auto sample_request = [&](int s, int backward) {
+    const bool tail = s == kSteps - 1;
+    const int nb = tail ? 192 : (32 * (s >> 2) + 4 * (s & 3));
+    const int dl = tail ? d_hi : d_lo;
+    const int nn = nb + dl + c0;                       // 1..200
+    if (backward) xb = lds[rowbase - dl + kNfft - nb - c0 + 1 + ((kNfft - nn) >= 2 * kHop ? 1 : 0)];
+    else xf = lds[rowbase + dl + nb + c0 + (nn >= kHop ? 1 : 0)];
+  };
+  const int gbase = 2 * cls * 128 + lane;              // float4 index of this class's first GEMM in a slot
+  Frag7 Ra[2], Rb[2];
+#pragma unroll
+  for (int g = 0; g < 2; ++g) Ra[g] = load_frag7(slots + gbase + g * 128);
+  sample_request(0, 0);
+  sample_request(0, 1);
+  __syncthreads();      // slot 0 is overwritten in the middle of step 0
+#pragma unroll
+  for (int s = 0; s < kSteps; ++s) {
+    Frag7(&Rc)[2] = (s & 1) ? Rb : Ra;
+    Frag7(&Rn)[2] = (s & 1) ? Ra : Rb;
+    const bool next = s + 1 < kSteps, stage = s + 2 < kSteps;
+    const f32x4* nslot = slots + ((s + 1) & 1) * 512 + gbase;
+    const float e = xf + xb, o = xf - xb;
+    f32x4(&Gw)[TW] = G[(s + 1) % 3];        // holds A(s+2), requested in step s-2
+    f32x4(&Gr)[TW] = G[s % 3];              // receives A(s+4)
+    constexpr int kReq = 2 * TW + 6;        // requests of a step, one behind each of its first MFMAs
+    auto request = [&](int i) {
+      if (i < TW) {
+        if (s + 4 < kSteps) Gr[i] = reinterpret_cast<const f32x4*>(a.dft_tab)[(s + 4) * 512 + NT * i + (unsigned)tid];
+      } else if (i < 2 * TW) {
+        if (stage) slots[(s & 1) * 512 + NT * (i - TW) + tid] = Gw[i - TW];
+      } else if (i < 2 * TW + 4) {
+        const int g = (i - 2 * TW) >> 1;
+        if (next) {
+          if ((i - 2 * TW) & 1) Rn[g].hi = *reinterpret_cast<const f32x3*>(nslot + g * 128 + 64);
+          else Rn[g].lo = nslot[g * 128];
+        }
+      } else if (next) {
+        sample_request(s + 1, i - (2 * TW + 4));
+      }
+    };
+#pragma unroll
+    for (int m = 0; m < 14; ++m) {
+      acc[m / 7][m % 7] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rc[m / 7].at(m % 7), (m / 7) ? o : e, acc[m / 7][m % 7], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (m < kReq) {
+        request(m);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (next) __syncthreads();
+  }
+  WFE_STAMP8(3);
+
+  // ---- mel weights of this wave's bin tiles (class 0: tiles 0-3, class 1: tiles 4-6), one batch
+  const f32x4* __restrict__ mtab = reinterpret_cast<const f32x4*>(a.mel_tab) + lane;
+  auto live = [](int f, int bt, int mt) {
+    return (((BANK == 1 ? kMelMask80[f * 7 + bt] : kMelMask128[f * 7 + bt]) >> mt) & 1u) != 0;
+  };
+  f32x4 m[NMT];
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt) m[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float* const xfg = lds + fg * 3584;                  // [A->B: 2 x 3 tiles | B->A: 2 x 4 tiles] x 4 regs x 64 lanes
+  __syncthreads();                                     // every wave is out of the k-loop: the image and the slots are dead
+
+  if (cls == 0) {
+    f32x4 wv[2][4][NMT];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int bt = 0; bt < 4; ++bt)
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+          if (live(f, bt, mt)) wv[f][bt][mt] = mtab[((f * 7 + bt) * kMelTiles + mt) * 64];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int bt = 4; bt < 7; ++bt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xfg[((g * 3 + (bt - 4)) * 4 + r) * 64 + lane] = acc[g][bt][r];
+    __syncthreads();
+#pragma unroll
+    for (int bt = 0; bt < 4; ++bt) {
+      f32x4 co, so;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        co[r] = xfg[1536 + ((0 * 4 + bt) * 4 + r) * 64 + lane];
+        so[r] = xfg[1536 + ((1 * 4 + bt) * 4 + r) * 64 + lane];
+      }
+      const f32x4 ce = acc[0][bt], se = acc[1][bt];
+      const f32x4 rp = ce + co, ip = se + so, rm = ce - co, im = se - so;
+      const f32x4 P0 = rp * rp + ip * ip, P1 = rm * rm + im * im;
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt) {
+        if (live(0, bt, mt)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) m[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0][bt][mt][r], P0[r], m[mt], 0, 0, 0);
+        }
+        if (live(1, bt, mt)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) m[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1][bt][mt][r], P1[r], m[mt], 0, 0, 0);
+        }
+      }
+    }
+  } else {
+    f32x4 wv[2][3][NMT];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int bt = 4; bt < 7; ++bt)
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+          if (live(f, bt, mt)) wv[f][bt - 4][mt] = mtab[((f * 7 + bt) * kMelTiles + mt) * 64];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int bt = 0; bt < 4; ++bt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xfg[1536 + ((g * 4 + bt) * 4 + r) * 64 + lane] = acc[g][bt][r];
+    __syncthreads();
+#pragma unroll
+    for (int bt = 4; bt < 7; ++bt) {
+      f32x4 ce, se;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        ce[r] = xfg[((0 * 3 + (bt - 4)) * 4 + r) * 64 + lane];
+        se[r] = xfg[((1 * 3 + (bt - 4)) * 4 + r) * 64 + lane];
+      }
+      const f32x4 co = acc[0][bt], so = acc[1][bt];
+      const f32x4 rp = ce + co, ip = se + so, rm = ce - co, im = se - so;
+      const f32x4 P0 = rp * rp + ip * ip, P1 = rm * rm + im * im;
+#pragma unroll
+      for (int mt = 0; mt < NMT; ++mt) {
+        if (live(0, bt, mt)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) m[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0][bt - 4][mt][r], P0[r], m[mt], 0, 0, 0);
+        }
+        if (live(1, bt, mt)) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) m[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1][bt - 4][mt][r], P1[r], m[mt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  WFE_STAMP8(4);
+  if (WFE_EXP & 1024) return;                          // diagnostic: no epilogue at all
+  // ---- each wave of the pair hands over its partial mel sums of the tiles the OTHER one
+  // finishes, then finishes its own: log10 (exact -10 at the floor, HF:159), (v + 4) / 4
+  // (the clamp of kernel 2 commutes with it), utterance max, minimum, and straight to
+  // HBM -- 16 frames of a mel row are one 64-byte run; no transposition, no further barrier.
+  if (!kYSeparate) __syncthreads();                    // Y overlays the exchange area: wait until it is read out
+  float* const ysum = lds + (kYSeparate ? kXFloats : 0) + fg * (NMT * 256);
+  if (cls == 0) {
+#pragma unroll
+    for (int mt = kOwn0; mt < NMT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ysum[(mt * 4 + r) * 64 + lane] = m[mt][r];
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < kOwn0; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ysum[(mt * 4 + r) * 64 + lane] = m[mt][r];
+  }
+  __syncthreads();
+  const int frame = t0 + fg * 16 + jl;
+  const bool frame_ok = frame < T;
+  float* __restrict__ lo = a.out + (long long)b * a.n_mel * T + frame;
+  float wmax = -INFINITY, wmin = INFINITY;
+  auto finish = [&](int mt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int mel = 16 * mt + 4 * kk + r;
+      const float pw = m[mt][r] + ysum[(mt * 4 + r) * 64 + lane];
+      const float v = (pw > 1e-10f) ? __builtin_amdgcn_logf(pw) * 0.30102999566398120f : -10.0f;
+      if (frame_ok && mel < a.n_mel) {
+        lo[(long long)mel * T] = (v + 4.0f) * 0.25f;
+        wmax = fmaxf(wmax, v);
+        wmin = fminf(wmin, v);
+      }
+    }
+  };
+  if (cls == 0) {
+#pragma unroll
+    for (int mt = 0; mt < kOwn0; ++mt) finish(mt);
+  } else {
+#pragma unroll
+    for (int mt = kOwn0; mt < NMT; ++mt) finish(mt);
+  }
+  if (WFE_EXP & 512) return;
+  wmax = wave_reduce<true>(wmax);
+  wmin = wave_reduce<false>(wmin);
+  if (lane == 0) {
+    if (wmax > -INFINITY) atomicMax(a.clip_max + b, enc_max(wmax));
+    a.block_min[(((long long)b * nblk + (t0 >> 6)) * 4 + ((t0 & 63) >> 4) + fg) * 2 + cls] = wmin;
+  }
+  WFE_STAMP8(5);
+}
+
 // ------------------------------------------------------------- kernel 2
 // log_spec = maximum(log_spec, max - 8.0); (log_spec + 4.0) / 4.0   (HF:160-165).
 // Kernel 1 already stored g(v) = (v + 4) / 4 and the minimum v of each of its
@@ -917,47 +1326,42 @@ __global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ out, con
                                                     const float* __restrict__ block_min, int n_mel, int T) {
   const int b = blockIdx.y;
   const float floor_v = dec_max(clip_max[b]) - 8.0f;
-  const float* bm = block_min + ((long long)b * gridDim.x + blockIdx.x) * 4;
-  const float lowest = fminf(fminf(bm[0], bm[1]), fminf(bm[2], bm[3]));
-  if (!(lowest < floor_v)) return;
-  const float floor_g = (floor_v + 4.0f) * 0.25f;
-  const int t0 = blockIdx.x * kBlockFrames;
-  const int frames_here = (T - t0 < kBlockFrames) ? (T - t0) : kBlockFrames;
-  float* __restrict__ p = out + (long long)b * n_mel * T + t0;
+  const float* bm = block_min + ((long long)b * gridDim.x + blockIdx.x) * 8;   // [frame group 4][wave of the pair 2]
+  // decided per half tile (32 frames): the 32-frame variant of kernel 1 marks silence per half
   const int tid = threadIdx.x;
+  const float floor_g = (floor_v + 4.0f) * 0.25f;
+  float* __restrict__ p = out + (long long)b * n_mel * T + blockIdx.x * kBlockFrames;
   const bool vec = (T & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
-  if (lowest == -INFINITY) {      // silent tile, left unwritten by kernel 1: every value is max(g(-10), g(max-8))
+  for (int h = 0; h < 2; ++h) {
+    const float lowest = fminf(fminf(bm[4 * h], bm[4 * h + 1]), fminf(bm[4 * h + 2], bm[4 * h + 3]));
+    if (!(lowest < floor_v)) continue;
+    const int t0 = blockIdx.x * kBlockFrames + 32 * h;
+    if (t0 >= T) continue;
+    const int frames_here = (T - t0 < 32) ? (T - t0) : 32;
+    float* __restrict__ ph = p + 32 * h;
+    const bool silent = lowest == -INFINITY;     // left unwritten by kernel 1: every value is max(g(-10), g(max-8))
     const float c = fmaxf(-1.5f, floor_g);
     if (vec) {
-      for (int idx = tid; idx < n_mel * (kBlockFrames / 4); idx += 256) {
-        const int mel = idx >> 4, c4 = idx & 15;
-        if (4 * c4 < frames_here) *reinterpret_cast<f32x4*>(p + (long long)mel * T + 4 * c4) = f32x4{c, c, c, c};
+      for (int idx = tid; idx < n_mel * 8; idx += 256) {
+        const int mel = idx >> 3, c4 = idx & 7;
+        if (4 * c4 < frames_here) {
+          f32x4* q = reinterpret_cast<f32x4*>(ph + (long long)mel * T + 4 * c4);
+          f32x4 v = f32x4{c, c, c, c};
+          if (!silent) {
+            v = *q;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], floor_g);
+          }
+          *q = v;
+        }
       }
     } else {
-      for (int idx = tid; idx < n_mel * kBlockFrames; idx += 256) {
-        const int mel = idx >> 6, fb = idx & 63;
-        if (fb < frames_here) p[(long long)mel * T + fb] = c;
-      }
-    }
-    return;
-  }
-  if (vec) {
-    for (int idx = tid; idx < n_mel * (kBlockFrames / 4); idx += 256) {
-      const int mel = idx >> 4, c4 = idx & 15;
-      if (4 * c4 < frames_here) {
-        f32x4* q =reinterpret_cast<f32x4*>(p + (long long)mel * T + 4 * c4);
-        f32x4 v = *q;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], floor_g);
-        *q = v;
-      }
-    }
-  } else {
-    for (int idx = tid; idx < n_mel * kBlockFrames; idx += 256) {
-      const int mel = idx >> 6, fb = idx & 63;
-      if (fb < frames_here) {
-        float* q = p + (long long)mel * T + fb;
-        *q = fmaxf(*q, floor_g);
+      for (int idx = tid; idx < n_mel * 32; idx += 256) {
+        const int mel = idx >> 5, fb = idx & 31;
+        if (fb < frames_here) {
+          float* q = ph + (long long)mel * T + fb;
+          *q = silent ? c : fmaxf(*q, floor_g);
+        }
       }
     }
   }
@@ -1309,7 +1713,19 @@ static hipError_t launch_k1(const FrontArgs& a, int batch, hipStream_t stream) {
 
 // bank: 1 = the 80-mel Whisper bank, 2 = the 128-mel bank (compile-time block
 // masks), 0 = any other feature_size (run-time masks).
-hipError_t launch_frontend(const FrontArgs& a, int batch, int mode, bool aug, int bank, hipStream_t stream) {
+template <int NMT, int BANK, int FG>
+static hipError_t launch_k1x8(const FrontArgs& a, int batch, hipStream_t stream) {
+  const dim3 grid((a.n_frames + 16 * FG - 1) / (16 * FG), batch);
+  hipLaunchKernelGGL((frontend8_kernel<NMT, BANK, FG>), grid, dim3(128 * FG), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_frontend(const FrontArgs& a, int batch, int mode, bool aug, int bank, hipStream_t stream,
+                           int variant) {
+  if (mode == 0 && !aug && variant == 2 && bank == 1) return launch_k1x8<5, 1, 2>(a, batch, stream);
+  if (mode == 0 && !aug && variant == 2 && bank == 2) return launch_k1x8<8, 2, 2>(a, batch, stream);
+  if (mode == 0 && !aug && variant == 8 && bank == 1) return launch_k1x8<5, 1, 4>(a, batch, stream);
+  if (mode == 0 && !aug && variant == 8 && bank == 2) return launch_k1x8<8, 2, 4>(a, batch, stream);
   if (mode == 1)
     return aug ? launch_k1<5, true, true, 0>(a, batch, stream) : launch_k1<5, true, false, 0>(a, batch, stream);
   if (bank == 1)
