@@ -908,6 +908,476 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   WFE_STAMP(5);
 }
 
+// ------------------------------------------- kernel 1, persistent variant
+// frontend_kernel's work per 64-frame tile, unchanged, inside a loop: the grid is
+// two workgroups per CU and workgroup g takes tiles g, g + G, g + 2G, ... of the
+// launch (tile = utterance * tiles-per-utterance + block).  What the loop buys: as soon
+// as a tile's mel MFMAs are issued its 112 accumulator registers are dead, and the
+// waveform of the NEXT tile (and its first twiddles) is requested into them, so
+// that the HBM round trip of the staging phase runs under the epilogue instead of
+// after it; and there is no workgroup turnover between tiles.  LDS regions are only
+// reused across barriers every wave passes: the image and the twiddle slots are
+// rewritten after the epilogue barrier of the previous tile (all waves are out of
+// its k-loop), the output tile has a region of its own (80 mel) or, where that does
+// not fit twice per CU (128 mel), overlays the slots behind one more barrier.
+template <int NMT, int BANK>
+__global__ __launch_bounds__(256, 2) void frontendp_kernel(const FrontArgs a, int n_tiles) {
+  static_assert(BANK == 1 || BANK == 2, "compile-time mel masks only");
+  constexpr bool POWER = false;
+  constexpr int kSlotFloats = 2 * kDftStepFloats;
+  constexpr int kTileFloats = 16 * NMT * kTileStride;
+  constexpr bool kTileSeparate = (kLdsWaveFloats + kSlotFloats + kTileFloats) * 4 <= 80 * 1024;
+  constexpr int kAuxFloats = kTileSeparate ? kSlotFloats + kTileFloats : (kTileFloats > kSlotFloats ? kTileFloats : kSlotFloats);
+  __shared__ __attribute__((aligned(16))) float lds[kLdsWaveFloats + kAuxFloats];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int n = a.n_samples;
+  const int T = a.n_frames;
+  const int nblk = (T + kBlockFrames - 1) / kBlockFrames;
+  f32x4* const slots = reinterpret_cast<f32x4*>(lds + kLdsWaveFloats);       // 2 x 512 float4
+  float* const tile = lds + kLdsWaveFloats + (kTileSeparate ? kSlotFloats : 0);   // [16 * NMT][kTileStride]
+  const f32x4* __restrict__ gtab = reinterpret_cast<const f32x4*>(a.dft_tab) + tid;
+
+  // what staging needs to know about a tile
+  struct TileInfo {
+    int b, blk, t0, p0, i_first, len;
+    Source src;
+    bool silent, interior, interior16;
+  };
+  auto decode = [&](int tile_id) {
+    TileInfo ti;
+    ti.b = tile_id / nblk;
+    ti.blk = tile_id - ti.b * nblk;
+    ti.t0 = ti.blk * kBlockFrames;
+    ti.p0 = ti.t0 * kHop;
+    ti.i_first = ti.p0 - kHalf;
+    ti.src = make_source(a, ti.b);
+    int len = a.lengths[ti.b];
+    if (len < 0) len = 0;
+    if (len > n) len = n;                       // truncation=True (HF:300-307)
+    ti.len = len;
+    const int i_last = ti.i_first + kBlockSamples - 1;
+    ti.silent = ti.i_first >= len && (i_last < n || 2 * (n - 1) - i_last >= len);
+    const bool inside = ti.i_first >= 0 && ti.i_first + kBlockSamples <= len;
+    ti.interior = inside && ti.src.w && ((reinterpret_cast<uintptr_t>(ti.src.w + ti.i_first) & 15u) == 0);
+    ti.interior16 = inside && ti.src.pcm && ti.src.ch == 1 &&
+                    ((reinterpret_cast<uintptr_t>(ti.src.pcm + ti.i_first) & 15u) == 0);
+    return ti;
+  };
+  // the interior loads of a tile: 11 x 16 bytes per thread (float32) or 6 (16-bit PCM), all in flight
+  constexpr int kIters = (kBlockSamples / 4 + 255) / 256;          // 11
+  constexpr int kIters16 = (kBlockSamples / 8 + 255) / 256;        // 6
+  using i32x4 = __attribute__((ext_vector_type(4))) int;
+  f32x4 buf[kIters];
+  auto issue_loads = [&](const TileInfo& ti) {
+    if (ti.interior16) {
+      const i32x4* __restrict__ src8 = reinterpret_cast<const i32x4*>(ti.src.pcm + ti.i_first);
+#pragma unroll
+      for (int it = 0; it < kIters16; ++it) {
+        int v8 = tid + 256 * it;                 // every lane loads (clamped): a lane-predicated load would
+        if (v8 > kBlockSamples / 8 - 1) v8 = kBlockSamples / 8 - 1;      // keep the register's old value alive
+        buf[it] = __builtin_bit_cast(f32x4, src8[v8]);
+      }
+#pragma unroll
+      for (int it = kIters16; it < kIters; ++it) buf[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else {
+      const f32x4* __restrict__ src4 = reinterpret_cast<const f32x4*>(ti.src.w + ti.i_first);
+#pragma unroll
+      for (int it = 0; it < kIters; ++it) {
+        int v4 = tid + 256 * it;
+        if (v4 > kBlockSamples / 4 - 1) v4 = kBlockSamples / 4 - 1;
+        buf[it] = src4[v4];
+      }
+    }
+  };
+  auto write_image = [&](const TileInfo& ti) {
+    if (ti.interior16) {
+      constexpr float kScale = 1.0f / 32768.0f;
+#pragma unroll
+      for (int it = 0; it < kIters16; ++it) {
+        const int v8 = tid + 256 * it;
+        if (v8 < kBlockSamples / 8) {
+          const int q = 8 * v8;                 // 8 | 160, so the eight share q / 160
+          const int base = q + q / kHop;
+          const i32x4 raw = __builtin_bit_cast(i32x4, buf[it]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            lds[base + 2 * j + 0] = (float)(short)(raw[j] & 0xffff) * kScale;
+            lds[base + 2 * j + 1] = (float)(raw[j] >> 16) * kScale;
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int it = 0; it < kIters; ++it) {
+        const int v4 = tid + 256 * it;
+        if (v4 < kBlockSamples / 4) {
+          const int q = 4 * v4;                 // 4 | 160, so the four share q / 160
+          const int base = q + q / kHop;
+          lds[base + 0] = buf[it][0];
+          lds[base + 1] = buf[it][1];
+          lds[base + 2] = buf[it][2];
+          lds[base + 3] = buf[it][3];
+        }
+      }
+    }
+  };
+  f32x4 g0, g1, g2, g3;
+  f32x4 ga[2], gb[2];                      // staging registers, ping-pong: A(s+2) / A(s+3)
+  auto issue_twiddles = [&]() {            // k-steps 0, 1 (-> the LDS slots) and 2 (-> ga)
+    g0 = gtab[0];
+    g1 = gtab[256];
+    g2 = gtab[512];
+    g3 = gtab[768];
+    ga[0] = gtab[1024];
+    ga[1] = gtab[1280];
+  };
+
+  // buf and g* are (re)defined on EVERY path at the end of a tile, so that they are dead --
+  // and their registers free -- during the k-loop
+  bool prefetched = false;                 // buf holds the current tile's waveform
+  bool first = true;
+  issue_twiddles();
+#pragma unroll
+  for (int it = 0; it < kIters; ++it) buf[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
+    const TileInfo ti = decode(tile_id);
+    const int b = ti.b, t0 = ti.t0;
+    // the table bases are re-read as opaque scalars in every tile: otherwise the ~70 per-thread
+    // 64-bit load addresses of the unrolled k-loop are hoisted out of the tile loop and spill
+    const float* dft_tab_it = a.dft_tab;
+    const float* mel_tab_it = a.mel_tab;
+    asm volatile("" : "+s"(dft_tab_it), "+s"(mel_tab_it));
+    WFE_STAMP(0);
+    if (ti.silent) {                       // see frontend_kernel: kernel 2 writes the tile
+      if (tid == 0) atomicMax(a.clip_max + b, enc_max(-10.0f));
+      if (tid < 8) a.block_min[((long long)b * nblk + ti.blk) * 8 + tid] = -INFINITY;
+      continue;                            // (a silent tile is never prefetched)
+    }
+    if (!prefetched && (ti.interior || ti.interior16)) issue_loads(ti);
+    if (first) {                           // stagger, once per workgroup: see frontend_kernel
+      first = false;
+      if (tid == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
+        const unsigned key = ((xcc & 15u) << 8) | ((hw >> 8) & 255u);
+        lds[0] = __uint_as_float(atomicAdd(a.cu_tickets + key, 1u));
+      }
+      __syncthreads();
+      const unsigned ticket = __float_as_uint(lds[0]);
+      __syncthreads();
+      if (ticket == 1u) {
+        __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_sleep(127);
+        __builtin_amdgcn_s_sleep(127);
+      }
+    }
+    if (ti.interior || ti.interior16) {
+      write_image(ti);
+    } else {
+      constexpr int kBatch = 7;                 // 41 positions per thread in 6 batches of 7
+      for (int q0 = tid; q0 < kBlockSamples; q0 += 256 * kBatch) {
+        float vals[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+          const int q = q0 + 256 * u;
+          int i = ti.p0 + q - kHalf;            // index into the length-n padded utterance
+          if (i < 0) i = -i;                    // torch.stft center=True, pad_mode="reflect"
+          if (i >= n) i = 2 * (n - 1) - i;
+          float v = 0.f;                        // right zero padding (padding_value 0.0)
+          if (q < kBlockSamples && i >= 0 && i < ti.len) v = ti.src.at(i);
+          vals[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+          const int q = q0 + 256 * u;
+          if (q < kBlockSamples) lds[pad_q(q)] = vals[u];
+        }
+      }
+    }
+    slots[tid] = g0;
+    slots[256 + tid] = g1;
+    slots[512 + tid] = g2;
+    slots[768 + tid] = g3;
+    WFE_STAMP(1);
+    __syncthreads();
+    WFE_STAMP(2);
+
+  // ---- folded DFT as 4 GEMMs on v_mfma_f32_16x16x4_f32
+  const int jl = lane & 15;
+  const int kk = lane >> 4;
+  const int d_lo = 2 * (kk >> 1) + 16 * (kk & 1);
+  const int d_hi = 2 * kk;
+  const int rowbase = 161 * (wave * 16 + jl);          // pad_q(160 * frame-in-block)
+
+  f32x4 acc[4][7];
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int bt = 0; bt < 7; ++bt) acc[g][bt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // The k-loop, fully unrolled (25 steps) so that every step-dependent index is a
+  // compile-time constant and the LDS addresses are lane base + immediate.  The
+  // twiddles of one k-step (8 KB) are shared by the 4 waves through a
+  // double-buffered LDS slot, so the CU's L1/TA path carries each of them once per
+  // workgroup instead of once per wave.  Everything a step consumes was requested
+  // a whole step earlier, and the requests are dealt out between the MFMAs of the
+  // step in four small batches so that the matrix pipe never waits on their issue:
+  //   step s:  MFMA 1,2    | global->reg A(s+3) (2 x 16 B/thread)
+  //            MFMA 3,4    | reg->LDS A(s+2) into slot s&1 (fetched during step s-1; the slot was
+  //                        |   read out in step s-1)
+  //            MFMA 5..12  | LDS->reg the 8 fragment pieces of A(s+1)
+  //            MFMA 13..16 | LDS->reg the 4 samples of step s+1
+  //            MFMA 17..28 | barrier
+  //   (one request behind each MFMA, pinned there)
+  // What keeps hipcc from serialising this (checked in the .s): the two fragment
+  // register sets ping-pong (a single set plus a copy gets the copy, and its wait,
+  // hoisted to a few MFMAs after the reads); scheduling barriers pin each batch
+  // (otherwise requests sink to their first use); the 8th, padding, twiddle is never
+  // read (a dead destination register is reused at once and forces a wait).
+  float xf[2], xb[2];
+  const int lane_lo = rowbase + d_lo, lane_hi = rowbase + d_hi;
+  auto sample_request = [&](int s, int c, int backward) {
+    // n = dft_n_of(c, s, kk) = nb + delta(lane) + c0, c0 = 2 (even class) or 1 (odd)
+    const bool tail = s == kSteps - 1;
+    const int nb = tail ? 192 : (32 * (s >> 2) + 4 * (s & 3));
+    const int dl = tail ? d_hi : d_lo;
+    const int base = tail ? lane_hi : lane_lo;
+    const int c0 = c ? 1 : 2;
+    const int nn = nb + dl + c0;                       // 1..200
+    const int mm = kNfft - nn;                         // 200..399
+    // pad_q(160 j + x) = 161 j + x + x / 160; the x / 160 term is a compile-time
+    // constant except in the few steps whose 4 k-lanes straddle 160 or 320
+    if (backward) xb[c] = lds[2 * rowbase - base + kNfft - nb - c0 + 1 + (mm >= 2 * kHop ? 1 : 0)];
+    else xf[c] = lds[base + nb + c0 + (nn >= kHop ? 1 : 0)];
+  };
+#ifdef WFE_STAMPS
+  unsigned long long barrier_cycles = 0;
+#endif
+  Frag7 Ra[4], Rb[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) Ra[g] = load_frag7(slots + lane + g * 128);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sample_request(0, i >> 1, i & 1);
+  __syncthreads();      // slot 0 is overwritten in the middle of step 0: every wave must have read it out
+#pragma unroll
+  for (int s = 0; s < kSteps; ++s) {
+    Frag7(&Rc)[4] = (s & 1) ? Rb : Ra;
+    Frag7(&Rn)[4] = (s & 1) ? Ra : Rb;
+    const bool next = s + 1 < kSteps, stage = s + 2 < kSteps;
+    const f32x4* nslot = slots + ((s + 1) & 1) * 512 + lane;
+    float e[2], o[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      e[c] = xf[c] + xb[c];
+      o[c] = xf[c] - xb[c];
+    }
+    auto mfma = [&](int g, int bt) {
+#ifdef WFE_AGPR_ACC
+      asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0"
+                   : "+a"(acc[g][bt])
+                   : "v"(Rc[g].at(bt)), "v"((g & 1) ? o[g >> 1] : e[g >> 1]));
+#else
+      acc[g][bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rc[g].at(bt), (g & 1) ? o[g >> 1] : e[g >> 1], acc[g][bt],
+                                                        0, 0, 0);
+#endif
+    };
+    f32x4(&Gw)[2] = (s & 1) ? gb : ga;      // holds A(s+2), requested during step s-1
+    f32x4(&Gr)[2] = (s & 1) ? ga : gb;      // receives A(s+3)
+    // the 16 requests of a step, one behind each of the first 16 MFMAs (a clump of
+    // them between two MFMAs idles the matrix pipe for the clump's issue time)
+#ifndef WFE_EXP
+#define WFE_EXP 0
+#endif
+    auto request = [&](int i) {
+      if (i < 2) {                                          // global -> registers, A(s+3)
+        // uniform base + 32-bit thread offset: a scalar-base load, no 64-bit VALU address math
+        if (s + 3 < kSteps && !(WFE_EXP & 1))
+          Gr[i] = reinterpret_cast<const f32x4*>(dft_tab_it)[(s + 3) * 512 + 256 * i + (unsigned)tid];
+      } else if (i < 4) {                                   // registers -> LDS, A(s+2)
+        if (stage && !(WFE_EXP & 2)) slots[(s & 1) * 512 + 256 * (i - 2) + tid] = Gw[i - 2];
+      } else if (i < 12) {                                  // LDS -> registers, fragments of A(s+1)
+        const int g = (i - 4) >> 1;
+        if (next && !(WFE_EXP & 4)) {
+          if ((i - 4) & 1) Rn[g].hi = *reinterpret_cast<const f32x3*>(nslot + g * 128 + 64);
+          else Rn[g].lo = nslot[g * 128];
+        }
+      } else if (next && !(WFE_EXP & 8)) {                  // LDS -> registers, samples of step s+1
+        sample_request(s + 1, (i - 12) >> 1, (i - 12) & 1);
+      }
+    };
+#pragma unroll
+    for (int m = 0; m < 28; ++m) {
+      mfma(m / 7, m % 7);
+      __builtin_amdgcn_sched_barrier(0);
+      if (m < 16) {
+        request(m);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#ifdef WFE_STAMPS
+    if (next) {
+      unsigned long long tb0, tb1;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb0)::"memory");
+      __syncthreads();
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb1)::"memory");
+      barrier_cycles += tb1 - tb0;
+    }
+#else
+    if (next) __syncthreads();
+#endif
+  }
+
+  WFE_STAMP(3);
+#if defined(WFE_STAMPS) && WFE_STAMPS == 1
+  if (a.stamps && lane == 0)
+    a.stamps[((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + blockIdx.x) * 4 + wave) * 8 + 7] = barrier_cycles;
+#endif
+  // Mel weight fragments of every live (bin tile, mel tile) block: all requested
+  // here, ahead of the butterflies, so that the mel phase pays one L2 round trip
+  // instead of one per block (the scheduling barrier pins the batch).
+  const f32x4* __restrict__ mtab = reinterpret_cast<const f32x4*>(mel_tab_it) + lane;
+  f32x4 wv[2][7][NMT];
+  if (!POWER && BANK != 0) {
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int bt = 0; bt < 7; ++bt)
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+          if (((BANK == 1 ? kMelMask80[f * 7 + bt] : kMelMask128[f * 7 + bt]) >> mt) & 1u)
+            wv[f][bt][mt] = mtab[((f * 7 + bt) * kMelTiles + mt) * 64];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // ---- butterflies + power: family 0 = bin k, family 1 = bin 200 - k
+  f32x4 P[2][7];
+#pragma unroll
+  for (int bt = 0; bt < 7; ++bt) {
+    const f32x4 ce = acc[0][bt], se = acc[1][bt], co = acc[2][bt], so = acc[3][bt];
+    const f32x4 rp = ce + co, ip = se + so, rm = ce - co, im = se - so;
+    P[0][bt] = rp * rp + ip * ip;
+    P[1][bt] = rm * rm + im * im;
+  }
+  const int frame = t0 + wave * 16 + jl;
+
+  if (POWER) {
+    float* __restrict__ po = a.out + (long long)b * kNfreq * T;
+#pragma unroll
+    for (int bt = 0; bt < 7; ++bt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k = 16 * bt + 4 * kk + r;
+        if (frame < T && k < kFoldBins) {
+          po[(long long)k * T + frame] = P[0][bt][r];
+          if (k < kFoldBins - 1) po[(long long)(200 - k) * T + frame] = P[1][bt][r];
+        }
+      }
+    return;
+  }
+
+  // ---- mel projection on the same MFMA; all-zero (bin tile, mel tile) blocks skipped
+  f32x4 m[NMT];
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt) m[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (BANK != 0) {
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int bt = 0; bt < 7; ++bt)
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt)
+          if (((BANK == 1 ? kMelMask80[f * 7 + bt] : kMelMask128[f * 7 + bt]) >> mt) & 1u) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              m[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[f][bt][mt][r], P[f][bt][r], m[mt], 0, 0, 0);
+          }
+  } else {
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int bt = 0; bt < 7; ++bt) {
+        const unsigned mask = a.mel_mask[f * 7 + bt];
+#pragma unroll
+        for (int mt = 0; mt < NMT; ++mt) {
+          if ((mask >> mt) & 1u) {
+            // uniform base + 32-bit lane offset: keeps the address in SGPRs (one VGPR
+            // pair per block would spill in this run-time-mask build)
+            const f32x4 w4 = reinterpret_cast<const f32x4*>(mel_tab_it)[((f * 7 + bt) * kMelTiles + mt) * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              m[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[r], P[f][bt][r], m[mt], 0, 0, 0);
+          }
+        }
+      }
+  }
+  WFE_STAMP(4);
+
+    // ---- the accumulators are dead: the next tile's waveform and first twiddles go into
+    // their registers now and arrive while this tile's epilogue runs
+    {
+      const int next_id = tile_id + gridDim.x;
+      const TileInfo nx = decode(next_id < n_tiles ? next_id : tile_id);
+      prefetched = next_id < n_tiles && !nx.silent && (nx.interior || nx.interior16);
+      issue_twiddles();
+      if (prefetched) {
+        issue_loads(nx);
+      } else {
+#pragma unroll
+        for (int it = 0; it < kIters; ++it) buf[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue: see frontend_kernel
+    float wmax = -INFINITY, wmin = INFINITY;
+    const bool frame_ok = frame < T;
+#pragma unroll
+    for (int mt = 0; mt < NMT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int mel = 16 * mt + 4 * kk + r;
+        const float pw = m[mt][r];
+        const float v = (pw > 1e-10f) ? __builtin_amdgcn_logf(pw) * 0.30102999566398120f : -10.0f;
+        tile[mel * kTileStride + wave * 16 + jl] = (v + 4.0f) * 0.25f;
+        if (frame_ok && mel < a.n_mel) {
+          wmax = fmaxf(wmax, v);
+          wmin = fminf(wmin, v);
+        }
+      }
+    wmax = wave_reduce<true>(wmax);
+    wmin = wave_reduce<false>(wmin);
+    if (lane == 0) {
+      if (wmax > -INFINITY) atomicMax(a.clip_max + b, enc_max(wmax));
+      a.block_min[((long long)b * nblk + ti.blk) * 8 + 2 * wave] = wmin;
+      a.block_min[((long long)b * nblk + ti.blk) * 8 + 2 * wave + 1] = wmin;
+    }
+    __syncthreads();
+    float* __restrict__ lo = a.out + (long long)b * a.n_mel * T + t0;
+    const int frames_here = (T - t0 < kBlockFrames) ? (T - t0) : kBlockFrames;
+    if ((T & 3) == 0 && (reinterpret_cast<uintptr_t>(lo) & 15u) == 0) {
+      constexpr int kIt = 16 * NMT / 16;                  // (16 NMT rows x 16 float4) / 256 threads
+      f32x4 row[kIt];
+#pragma unroll
+      for (int it = 0; it < kIt; ++it)
+        row[it] = *reinterpret_cast<const f32x4*>(tile + (it * 16 + (tid >> 4)) * kTileStride + 4 * (tid & 15));
+#pragma unroll
+      for (int it = 0; it < kIt; ++it) {
+        const int mel = it * 16 + (tid >> 4), c4 = tid & 15;
+        if (mel < a.n_mel && 4 * c4 < frames_here)        // T % 4 == 0: a float4 is all-valid or all-out
+          *reinterpret_cast<f32x4*>(lo + (long long)mel * T + 4 * c4) = row[it];
+      }
+    } else {
+      for (int idx = tid; idx < a.n_mel * kBlockFrames; idx += 256) {
+        const int mel = idx >> 6, fb = idx & 63;
+        if (fb < frames_here) lo[(long long)mel * T + fb] = tile[mel * kTileStride + fb];
+      }
+    }
+    if (!kTileSeparate) __syncthreads();   // the output tile overlays the twiddle slots the next tile fills
+    WFE_STAMP(5);
+  }
+}
+
 // ------------------------------------------------ kernel 1, 8-wave variant
 // Same transform, same tables, same LDS waveform image, but the 64 frames of a
 // workgroup are worked by EIGHT waves: wave = (frame group fg = wave & 3, parity
@@ -1713,6 +2183,15 @@ static hipError_t launch_k1(const FrontArgs& a, int batch, hipStream_t stream) {
 
 // bank: 1 = the 80-mel Whisper bank, 2 = the 128-mel bank (compile-time block
 // masks), 0 = any other feature_size (run-time masks).
+template <int NMT, int BANK>
+static hipError_t launch_k1p(const FrontArgs& a, int batch, hipStream_t stream) {
+  const long long n_tiles = (long long)batch * ((a.n_frames + kBlockFrames - 1) / kBlockFrames);
+  long long grid = 2LL * (a.cu_count > 0 ? a.cu_count : 256);       // two resident workgroups per CU
+  if (grid > n_tiles) grid = n_tiles;
+  hipLaunchKernelGGL((frontendp_kernel<NMT, BANK>), dim3((unsigned)grid), dim3(256), 0, stream, a, (int)n_tiles);
+  return hipGetLastError();
+}
+
 template <int NMT, int BANK, int FG>
 static hipError_t launch_k1x8(const FrontArgs& a, int batch, hipStream_t stream) {
   const dim3 grid((a.n_frames + 16 * FG - 1) / (16 * FG), batch);
@@ -1722,6 +2201,8 @@ static hipError_t launch_k1x8(const FrontArgs& a, int batch, hipStream_t stream)
 
 hipError_t launch_frontend(const FrontArgs& a, int batch, int mode, bool aug, int bank, hipStream_t stream,
                            int variant) {
+  if (mode == 0 && !aug && variant == 1 && bank == 1) return launch_k1p<5, 1>(a, batch, stream);
+  if (mode == 0 && !aug && variant == 1 && bank == 2) return launch_k1p<8, 2>(a, batch, stream);
   if (mode == 0 && !aug && variant == 2 && bank == 1) return launch_k1x8<5, 1, 2>(a, batch, stream);
   if (mode == 0 && !aug && variant == 2 && bank == 2) return launch_k1x8<8, 2, 2>(a, batch, stream);
   if (mode == 0 && !aug && variant == 8 && bank == 1) return launch_k1x8<5, 1, 4>(a, batch, stream);
