@@ -145,23 +145,3 @@ def test_full_batch_properties(fes):
     assert bool(((mx - mn) <= 2.0 + 1e-6).all())
     want = ol.logmel_f32(list(base[:2]), n_mel=80)
     assert np.abs(solo[:2].cpu().numpy() - want).max() <= TOL
-
-
-@pytest.mark.parametrize("variant", ["8", "2"])
-def test_class_split_kernel_variants_agree(variant, monkeypatch):
-    """The experimental 8-wave / 4x32-frame class-split variants of kernel 1 (WFE_K1,
-    read at wfe_create) against the default kernel: same tables, same k order per
-    accumulator, only the mel partial sums are added in a different order."""
-    from wfe_amd.frontend import HipFrontEnd, pack_ragged
-    waves = [cases.bench_clip(60 + i, n) for i, n in enumerate((480000, 123457, 600000, 5000, 0, 31999, 32161))]
-    for n_mel in (80, 128):
-        monkeypatch.delenv("WFE_K1", raising=False)
-        base = HipFrontEnd(n_mel=n_mel, device=0)
-        monkeypatch.setenv("WFE_K1", variant)
-        other = HipFrontEnd(n_mel=n_mel, device=0)
-        flat, off, lens = pack_ragged(waves, base.device)
-        for n_samples in (480000, 32000, 5120 + 160):
-            a = base.logmel(flat, lens, n_samples=n_samples, offsets=off)
-            b = other.logmel(flat, lens, n_samples=n_samples, offsets=off)
-            torch.cuda.synchronize()
-            assert (a - b).abs().max().item() <= 2e-6

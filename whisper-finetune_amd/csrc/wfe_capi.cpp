@@ -42,8 +42,6 @@ struct wfe_context {
     int L = 0, M = 0, taps = 0, k0 = 0;
   };
   std::map<std::pair<int, int>, RsTable> rs_tables;   // (in_rate, out_rate) -> filter on the device
-  int cu_count = 256;
-  int k1_variant = 4;                       // WFE_K1=4 | 8 | 2 selects the kernel-1 variant (A/B runs; 4 is the fastest)
   float* d_block_min = nullptr;             // per-wave minima of kernel 1, grows on demand
   size_t block_min_cap = 0;
   unsigned long long* d_stamps = nullptr;   // diagnostic builds only (wfe_debug_stamps)
@@ -120,7 +118,6 @@ void fill_args(wfe_context* h, wfe::FrontArgs& a, const void* wav_or_pcm, int ch
   a.clip_max = h->d_clip_max;
   a.cu_tickets = h->d_clip_max + kMaxBatchPerLaunch;
   a.block_min = h->d_block_min;
-  a.cu_count = h->cu_count;
   a.stamps = h->d_stamps;
 }
 
@@ -229,7 +226,7 @@ int run_frontend(wfe_context* h, const void* wav, int channels, const int64_t* o
       h->ev_used += 3;
       HIP_TRY(h, hipEventRecord(ev[0], stream));
     }
-    HIP_TRY(h, wfe::launch_frontend(a, s.count, mode, aug, h->bank, stream, h->k1_variant));
+    HIP_TRY(h, wfe::launch_frontend(a, s.count, mode, aug, h->bank, stream));
     if (ev) HIP_TRY(h, hipEventRecord(ev[1], stream));
     if (mode == 0)
       HIP_TRY(h, wfe::launch_clamp(a.out, h->d_clip_max, h->d_block_min, s.count, h->cfg.n_mel, T, stream));
@@ -276,12 +273,7 @@ int wfe_create(const wfe_config* cfg, wfe_handle* out) {
   wfe_build_mel_table(cfg->n_mel, mel.data(), h->mel_mask);
   if (cfg->n_mel == 80 && std::memcmp(h->mel_mask, wfe::kMelMask80, sizeof h->mel_mask) == 0) h->bank = 1;
   if (cfg->n_mel == 128 && std::memcmp(h->mel_mask, wfe::kMelMask128, sizeof h->mel_mask) == 0) h->bank = 2;
-  if (const char* k1 = std::getenv("WFE_K1")) h->k1_variant = std::atoi(k1);
-  {
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, cfg->device) == hipSuccess && cus > 0)
-      h->cu_count = cus;
-  }
+
 
   DeviceGuard guard(cfg->device);
   hipError_t e = guard.ok ? hipSuccess : hipErrorInvalidDevice;

@@ -34,7 +34,6 @@ struct FrontArgs {
   float* out;                    // (B, n_mel, T) log10 mel power, or (B, 201, T) power
   unsigned* clip_max;            // (B) order-preserving encoding of max log10
   float* block_min;              // (B x 64-frame tiles x 4 frame groups x 2) minimum log10 mel seen by each wave
-  int cu_count;                  // compute units of the device (grid of the persistent variant)
   unsigned* cu_tickets;          // (4096) arrival counters per CU, zeroed with clip_max (stagger heuristic)
   // augmentation (AUG kernels only)
   const wfe_aug_op* ops;
@@ -47,12 +46,7 @@ struct FrontArgs {
 };
 
 // mode 0: log10 mel + clip max.  mode 1: power spectrum.
-// variant: 1 = frontendp_kernel (frontend_kernel's tile inside a persistent loop with next-tile prefetch;
-// Whisper banks, no augmentation); 4 = frontend_kernel (4 waves x 16 frames, all four GEMMs per wave); 8 / 2 = the class-split
-// frontend8_kernel with 8 waves x 64 frames / 4 waves x 32 frames, where it exists (Whisper banks, no
-// augmentation); anything else falls back to frontend_kernel
-hipError_t launch_frontend(const FrontArgs& a, int batch, int mode, bool augmented, int bank, hipStream_t stream,
-                           int variant);
+hipError_t launch_frontend(const FrontArgs& a, int batch, int mode, bool augmented, int bank, hipStream_t stream);
 // max(stored, g(max-8)) over the tiles whose minimum is below max-8 (kernel 1 stored g(v) = (v+4)/4)
 hipError_t launch_clamp(float* out, const unsigned* clip_max, const float* block_min, int batch, int n_mel,
                         int n_frames, hipStream_t stream);

@@ -908,884 +908,6 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   WFE_STAMP(5);
 }
 
-// ------------------------------------------- kernel 1, persistent variant
-// frontend_kernel's work per 64-frame tile, unchanged, inside a loop: the grid is
-// two workgroups per CU and workgroup g takes tiles g, g + G, g + 2G, ... of the
-// launch (tile = utterance * tiles-per-utterance + block).  What the loop buys: as soon
-// as a tile's mel MFMAs are issued its 112 accumulator registers are dead, and the
-// waveform of the NEXT tile (and its first twiddles) is requested into them, so
-// that the HBM round trip of the staging phase runs under the epilogue instead of
-// after it; and there is no workgroup turnover between tiles.  LDS regions are only
-// reused across barriers every wave passes: the image and the twiddle slots are
-// rewritten after the epilogue barrier of the previous tile (all waves are out of
-// its k-loop), the output tile has a region of its own (80 mel) or, where that does
-// not fit twice per CU (128 mel), overlays the slots behind one more barrier.
-template <int NMT, int BANK>
-__global__ __launch_bounds__(256, 2) void frontendp_kernel(const FrontArgs a, int n_tiles) {
-  static_assert(BANK == 1 || BANK == 2, "compile-time mel masks only");
-  constexpr bool POWER = false;
-  constexpr int kSlotFloats = 2 * kDftStepFloats;
-  constexpr int kTileFloats = 16 * NMT * kTileStride;
-  constexpr bool kTileSeparate = (kLdsWaveFloats + kSlotFloats + kTileFloats) * 4 <= 80 * 1024;
-  constexpr int kAuxFloats = kTileSeparate ? kSlotFloats + kTileFloats : (kTileFloats > kSlotFloats ? kTileFloats : kSlotFloats);
-  __shared__ __attribute__((aligned(16))) float lds[kLdsWaveFloats + kAuxFloats];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int n = a.n_samples;
-  const int T = a.n_frames;
-  const int nblk = (T + kBlockFrames - 1) / kBlockFrames;
-  f32x4* const slots = reinterpret_cast<f32x4*>(lds + kLdsWaveFloats);       // 2 x 512 float4
-  float* const tile = lds + kLdsWaveFloats + (kTileSeparate ? kSlotFloats : 0);   // [16 * NMT][kTileStride]
-  const f32x4* __restrict__ gtab = reinterpret_cast<const f32x4*>(a.dft_tab) + tid;
-
-  // what staging needs to know about a tile
-  struct TileInfo {
-    int b, blk, t0, p0, i_first, len;
-    Source src;
-    bool silent, interior, interior16;
-  };
-  auto decode = [&](int tile_id) {
-    TileInfo ti;
-    ti.b = tile_id / nblk;
-    ti.blk = tile_id - ti.b * nblk;
-    ti.t0 = ti.blk * kBlockFrames;
-    ti.p0 = ti.t0 * kHop;
-    ti.i_first = ti.p0 - kHalf;
-    ti.src = make_source(a, ti.b);
-    int len = a.lengths[ti.b];
-    if (len < 0) len = 0;
-    if (len > n) len = n;                       // truncation=True (HF:300-307)
-    ti.len = len;
-    const int i_last = ti.i_first + kBlockSamples - 1;
-    ti.silent = ti.i_first >= len && (i_last < n || 2 * (n - 1) - i_last >= len);
-    const bool inside = ti.i_first >= 0 && ti.i_first + kBlockSamples <= len;
-    ti.interior = inside && ti.src.w && ((reinterpret_cast<uintptr_t>(ti.src.w + ti.i_first) & 15u) == 0);
-    ti.interior16 = inside && ti.src.pcm && ti.src.ch == 1 &&
-                    ((reinterpret_cast<uintptr_t>(ti.src.pcm + ti.i_first) & 15u) == 0);
-    return ti;
-  };
-  // the interior loads of a tile: 11 x 16 bytes per thread (float32) or 6 (16-bit PCM), all in flight
-  constexpr int kIters = (kBlockSamples / 4 + 255) / 256;          // 11
-  constexpr int kIters16 = (kBlockSamples / 8 + 255) / 256;        // 6
-  using i32x4 = __attribute__((ext_vector_type(4))) int;
-  f32x4 buf[kIters];
-  auto issue_loads = [&](const TileInfo& ti) {
-    if (ti.interior16) {
-      const i32x4* __restrict__ src8 = reinterpret_cast<const i32x4*>(ti.src.pcm + ti.i_first);
-#pragma unroll
-      for (int it = 0; it < kIters16; ++it) {
-        int v8 = tid + 256 * it;                 // every lane loads (clamped): a lane-predicated load would
-        if (v8 > kBlockSamples / 8 - 1) v8 = kBlockSamples / 8 - 1;      // keep the register's old value alive
-        buf[it] = __builtin_bit_cast(f32x4, src8[v8]);
-      }
-#pragma unroll
-      for (int it = kIters16; it < kIters; ++it) buf[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-    } else {
-      const f32x4* __restrict__ src4 = reinterpret_cast<const f32x4*>(ti.src.w + ti.i_first);
-#pragma unroll
-      for (int it = 0; it < kIters; ++it) {
-        int v4 = tid + 256 * it;
-        if (v4 > kBlockSamples / 4 - 1) v4 = kBlockSamples / 4 - 1;
-        buf[it] = src4[v4];
-      }
-    }
-  };
-  auto write_image = [&](const TileInfo& ti) {
-    if (ti.interior16) {
-      constexpr float kScale = 1.0f / 32768.0f;
-#pragma unroll
-      for (int it = 0; it < kIters16; ++it) {
-        const int v8 = tid + 256 * it;
-        if (v8 < kBlockSamples / 8) {
-          const int q = 8 * v8;                 // 8 | 160, so the eight share q / 160
-          const int base = q + q / kHop;
-          const i32x4 raw = __builtin_bit_cast(i32x4, buf[it]);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            lds[base + 2 * j + 0] = (float)(short)(raw[j] & 0xffff) * kScale;
-            lds[base + 2 * j + 1] = (float)(raw[j] >> 16) * kScale;
-          }
-        }
-      }
-    } else {
-#pragma unroll
-      for (int it = 0; it < kIters; ++it) {
-        const int v4 = tid + 256 * it;
-        if (v4 < kBlockSamples / 4) {
-          const int q = 4 * v4;                 // 4 | 160, so the four share q / 160
-          const int base = q + q / kHop;
-          lds[base + 0] = buf[it][0];
-          lds[base + 1] = buf[it][1];
-          lds[base + 2] = buf[it][2];
-          lds[base + 3] = buf[it][3];
-        }
-      }
-    }
-  };
-  f32x4 g0, g1, g2, g3;
-  f32x4 ga[2], gb[2];                      // staging registers, ping-pong: A(s+2) / A(s+3)
-  auto issue_twiddles = [&]() {            // k-steps 0, 1 (-> the LDS slots) and 2 (-> ga)
-    g0 = gtab[0];
-    g1 = gtab[256];
-    g2 = gtab[512];
-    g3 = gtab[768];
-    ga[0] = gtab[1024];
-    ga[1] = gtab[1280];
-  };
-
-  // buf and g* are (re)defined on EVERY path at the end of a tile, so that they are dead --
-  // and their registers free -- during the k-loop
-  bool prefetched = false;                 // buf holds the current tile's waveform
-  bool first = true;
-  issue_twiddles();
-#pragma unroll
-  for (int it = 0; it < kIters; ++it) buf[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int tile_id = blockIdx.x; tile_id < n_tiles; tile_id += gridDim.x) {
-    const TileInfo ti = decode(tile_id);
-    const int b = ti.b, t0 = ti.t0;
-    // the table bases are re-read as opaque scalars in every tile: otherwise the ~70 per-thread
-    // 64-bit load addresses of the unrolled k-loop are hoisted out of the tile loop and spill
-    const float* dft_tab_it = a.dft_tab;
-    const float* mel_tab_it = a.mel_tab;
-    asm volatile("" : "+s"(dft_tab_it), "+s"(mel_tab_it));
-    WFE_STAMP(0);
-    if (ti.silent) {                       // see frontend_kernel: kernel 2 writes the tile
-      if (tid == 0) atomicMax(a.clip_max + b, enc_max(-10.0f));
-      if (tid < 8) a.block_min[((long long)b * nblk + ti.blk) * 8 + tid] = -INFINITY;
-      continue;                            // (a silent tile is never prefetched)
-    }
-    if (!prefetched && (ti.interior || ti.interior16)) issue_loads(ti);
-    if (first) {                           // stagger, once per workgroup: see frontend_kernel
-      first = false;
-      if (tid == 0) {
-        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
-        const unsigned key = ((xcc & 15u) << 8) | ((hw >> 8) & 255u);
-        lds[0] = __uint_as_float(atomicAdd(a.cu_tickets + key, 1u));
-      }
-      __syncthreads();
-      const unsigned ticket = __float_as_uint(lds[0]);
-      __syncthreads();
-      if (ticket == 1u) {
-        __builtin_amdgcn_s_sleep(127);
-        __builtin_amdgcn_s_sleep(127);
-        __builtin_amdgcn_s_sleep(127);
-      }
-    }
-    if (ti.interior || ti.interior16) {
-      write_image(ti);
-    } else {
-      constexpr int kBatch = 7;                 // 41 positions per thread in 6 batches of 7
-      for (int q0 = tid; q0 < kBlockSamples; q0 += 256 * kBatch) {
-        float vals[kBatch];
-#pragma unroll
-        for (int u = 0; u < kBatch; ++u) {
-          const int q = q0 + 256 * u;
-          int i = ti.p0 + q - kHalf;            // index into the length-n padded utterance
-          if (i < 0) i = -i;                    // torch.stft center=True, pad_mode="reflect"
-          if (i >= n) i = 2 * (n - 1) - i;
-          float v = 0.f;                        // right zero padding (padding_value 0.0)
-          if (q < kBlockSamples && i >= 0 && i < ti.len) v = ti.src.at(i);
-          vals[u] = v;
-        }
-#pragma unroll
-        for (int u = 0; u < kBatch; ++u) {
-          const int q = q0 + 256 * u;
-          if (q < kBlockSamples) lds[pad_q(q)] = vals[u];
-        }
-      }
-    }
-    slots[tid] = g0;
-    slots[256 + tid] = g1;
-    slots[512 + tid] = g2;
-    slots[768 + tid] = g3;
-    WFE_STAMP(1);
-    __syncthreads();
-    WFE_STAMP(2);
-
-  // ---- folded DFT as 4 GEMMs on v_mfma_f32_16x16x4_f32
-  const int jl = lane & 15;
-  const int kk = lane >> 4;
-  const int d_lo = 2 * (kk >> 1) + 16 * (kk & 1);
-  const int d_hi = 2 * kk;
-  const int rowbase = 161 * (wave * 16 + jl);          // pad_q(160 * frame-in-block)
-
-  f32x4 acc[4][7];
-#pragma unroll
-  for (int g = 0; g < 4; ++g)
-#pragma unroll
-    for (int bt = 0; bt < 7; ++bt) acc[g][bt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // The k-loop, fully unrolled (25 steps) so that every step-dependent index is a
-  // compile-time constant and the LDS addresses are lane base + immediate.  The
-  // twiddles of one k-step (8 KB) are shared by the 4 waves through a
-  // double-buffered LDS slot, so the CU's L1/TA path carries each of them once per
-  // workgroup instead of once per wave.  Everything a step consumes was requested
-  // a whole step earlier, and the requests are dealt out between the MFMAs of the
-  // step in four small batches so that the matrix pipe never waits on their issue:
-  //   step s:  MFMA 1,2    | global->reg A(s+3) (2 x 16 B/thread)
-  //            MFMA 3,4    | reg->LDS A(s+2) into slot s&1 (fetched during step s-1; the slot was
-  //                        |   read out in step s-1)
-  //            MFMA 5..12  | LDS->reg the 8 fragment pieces of A(s+1)
-  //            MFMA 13..16 | LDS->reg the 4 samples of step s+1
-  //            MFMA 17..28 | barrier
-  //   (one request behind each MFMA, pinned there)
-  // What keeps hipcc from serialising this (checked in the .s): the two fragment
-  // register sets ping-pong (a single set plus a copy gets the copy, and its wait,
-  // hoisted to a few MFMAs after the reads); scheduling barriers pin each batch
-  // (otherwise requests sink to their first use); the 8th, padding, twiddle is never
-  // read (a dead destination register is reused at once and forces a wait).
-  float xf[2], xb[2];
-  const int lane_lo = rowbase + d_lo, lane_hi = rowbase + d_hi;
-  auto sample_request = [&](int s, int c, int backward) {
-    // n = dft_n_of(c, s, kk) = nb + delta(lane) + c0, c0 = 2 (even class) or 1 (odd)
-    const bool tail = s == kSteps - 1;
-    const int nb = tail ? 192 : (32 * (s >> 2) + 4 * (s & 3));
-    const int dl = tail ? d_hi : d_lo;
-    const int base = tail ? lane_hi : lane_lo;
-    const int c0 = c ? 1 : 2;
-    const int nn = nb + dl + c0;                       // 1..200
-    const int mm = kNfft - nn;                         // 200..399
-    // pad_q(160 j + x) = 161 j + x + x / 160; the x / 160 term is a compile-time
-    // constant except in the few steps whose 4 k-lanes straddle 160 or 320
-    if (backward) xb[c] = lds[2 * rowbase - base + kNfft - nb - c0 + 1 + (mm >= 2 * kHop ? 1 : 0)];
-    else xf[c] = lds[base + nb + c0 + (nn >= kHop ? 1 : 0)];
-  };
-#ifdef WFE_STAMPS
-  unsigned long long barrier_cycles = 0;
-#endif
-  Frag7 Ra[4], Rb[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) Ra[g] = load_frag7(slots + lane + g * 128);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) sample_request(0, i >> 1, i & 1);
-  __syncthreads();      // slot 0 is overwritten in the middle of step 0: every wave must have read it out
-#pragma unroll
-  for (int s = 0; s < kSteps; ++s) {
-    Frag7(&Rc)[4] = (s & 1) ? Rb : Ra;
-    Frag7(&Rn)[4] = (s & 1) ? Ra : Rb;
-    const bool next = s + 1 < kSteps, stage = s + 2 < kSteps;
-    const f32x4* nslot = slots + ((s + 1) & 1) * 512 + lane;
-    float e[2], o[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      e[c] = xf[c] + xb[c];
-      o[c] = xf[c] - xb[c];
-    }
-    auto mfma = [&](int g, int bt) {
-#ifdef WFE_AGPR_ACC
-      asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0"
-                   : "+a"(acc[g][bt])
-                   : "v"(Rc[g].at(bt)), "v"((g & 1) ? o[g >> 1] : e[g >> 1]));
-#else
-      acc[g][bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rc[g].at(bt), (g & 1) ? o[g >> 1] : e[g >> 1], acc[g][bt],
-                                                        0, 0, 0);
-#endif
-    };
-    f32x4(&Gw)[2] = (s & 1) ? gb : ga;      // holds A(s+2), requested during step s-1
-    f32x4(&Gr)[2] = (s & 1) ? ga : gb;      // receives A(s+3)
-    // the 16 requests of a step, one behind each of the first 16 MFMAs (a clump of
-    // them between two MFMAs idles the matrix pipe for the clump's issue time)
-#ifndef WFE_EXP
-#define WFE_EXP 0
-#endif
-    auto request = [&](int i) {
-      if (i < 2) {                                          // global -> registers, A(s+3)
-        // uniform base + 32-bit thread offset: a scalar-base load, no 64-bit VALU address math
-        if (s + 3 < kSteps && !(WFE_EXP & 1))
-          Gr[i] = reinterpret_cast<const f32x4*>(dft_tab_it)[(s + 3) * 512 + 256 * i + (unsigned)tid];
-      } else if (i < 4) {                                   // registers -> LDS, A(s+2)
-        if (stage && !(WFE_EXP & 2)) slots[(s & 1) * 512 + 256 * (i - 2) + tid] = Gw[i - 2];
-      } else if (i < 12) {                                  // LDS -> registers, fragments of A(s+1)
-        const int g = (i - 4) >> 1;
-        if (next && !(WFE_EXP & 4)) {
-          if ((i - 4) & 1) Rn[g].hi = *reinterpret_cast<const f32x3*>(nslot + g * 128 + 64);
-          else Rn[g].lo = nslot[g * 128];
-        }
-      } else if (next && !(WFE_EXP & 8)) {                  // LDS -> registers, samples of step s+1
-        sample_request(s + 1, (i - 12) >> 1, (i - 12) & 1);
-      }
-    };
-#pragma unroll
-    for (int m = 0; m < 28; ++m) {
-      mfma(m / 7, m % 7);
-      __builtin_amdgcn_sched_barrier(0);
-      if (m < 16) {
-        request(m);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-#ifdef WFE_STAMPS
-    if (next) {
-      unsigned long long tb0, tb1;
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb0)::"memory");
-      __syncthreads();
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb1)::"memory");
-      barrier_cycles += tb1 - tb0;
-    }
-#else
-    if (next) __syncthreads();
-#endif
-  }
-
-  WFE_STAMP(3);
-#if defined(WFE_STAMPS) && WFE_STAMPS == 1
-  if (a.stamps && lane == 0)
-    a.stamps[((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + blockIdx.x) * 4 + wave) * 8 + 7] = barrier_cycles;
-#endif
-  // Mel weight fragments of every live (bin tile, mel tile) block: all requested
-  // here, ahead of the butterflies, so that the mel phase pays one L2 round trip
-  // instead of one per block (the scheduling barrier pins the batch).
-  const f32x4* __restrict__ mtab = reinterpret_cast<const f32x4*>(mel_tab_it) + lane;
-  f32x4 wv[2][7][NMT];
-  if (!POWER && BANK != 0) {
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-      for (int bt = 0; bt < 7; ++bt)
-#pragma unroll
-        for (int mt = 0; mt < NMT; ++mt)
-          if (((BANK == 1 ? kMelMask80[f * 7 + bt] : kMelMask128[f * 7 + bt]) >> mt) & 1u)
-            wv[f][bt][mt] = mtab[((f * 7 + bt) * kMelTiles + mt) * 64];
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  // ---- butterflies + power: family 0 = bin k, family 1 = bin 200 - k
-  f32x4 P[2][7];
-#pragma unroll
-  for (int bt = 0; bt < 7; ++bt) {
-    const f32x4 ce = acc[0][bt], se = acc[1][bt], co = acc[2][bt], so = acc[3][bt];
-    const f32x4 rp = ce + co, ip = se + so, rm = ce - co, im = se - so;
-    P[0][bt] = rp * rp + ip * ip;
-    P[1][bt] = rm * rm + im * im;
-  }
-  const int frame = t0 + wave * 16 + jl;
-
-  if (POWER) {
-    float* __restrict__ po = a.out + (long long)b * kNfreq * T;
-#pragma unroll
-    for (int bt = 0; bt < 7; ++bt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int k = 16 * bt + 4 * kk + r;
-        if (frame < T && k < kFoldBins) {
-          po[(long long)k * T + frame] = P[0][bt][r];
-          if (k < kFoldBins - 1) po[(long long)(200 - k) * T + frame] = P[1][bt][r];
-        }
-      }
-    return;
-  }
-
-  // ---- mel projection on the same MFMA; all-zero (bin tile, mel tile) blocks skipped
-  f32x4 m[NMT];
-#pragma unroll
-  for (int mt = 0; mt < NMT; ++mt) m[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (BANK != 0) {
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-      for (int bt = 0; bt < 7; ++bt)
-#pragma unroll
-        for (int mt = 0; mt < NMT; ++mt)
-          if (((BANK == 1 ? kMelMask80[f * 7 + bt] : kMelMask128[f * 7 + bt]) >> mt) & 1u) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              m[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[f][bt][mt][r], P[f][bt][r], m[mt], 0, 0, 0);
-          }
-  } else {
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-      for (int bt = 0; bt < 7; ++bt) {
-        const unsigned mask = a.mel_mask[f * 7 + bt];
-#pragma unroll
-        for (int mt = 0; mt < NMT; ++mt) {
-          if ((mask >> mt) & 1u) {
-            // uniform base + 32-bit lane offset: keeps the address in SGPRs (one VGPR
-            // pair per block would spill in this run-time-mask build)
-            const f32x4 w4 = reinterpret_cast<const f32x4*>(mel_tab_it)[((f * 7 + bt) * kMelTiles + mt) * 64 + lane];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              m[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[r], P[f][bt][r], m[mt], 0, 0, 0);
-          }
-        }
-      }
-  }
-  WFE_STAMP(4);
-
-    // ---- the accumulators are dead: the next tile's waveform and first twiddles go into
-    // their registers now and arrive while this tile's epilogue runs
-    {
-      const int next_id = tile_id + gridDim.x;
-      const TileInfo nx = decode(next_id < n_tiles ? next_id : tile_id);
-      prefetched = next_id < n_tiles && !nx.silent && (nx.interior || nx.interior16);
-      issue_twiddles();
-      if (prefetched) {
-        issue_loads(nx);
-      } else {
-#pragma unroll
-        for (int it = 0; it < kIters; ++it) buf[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-
-    // ---- epilogue: see frontend_kernel
-    float wmax = -INFINITY, wmin = INFINITY;
-    const bool frame_ok = frame < T;
-#pragma unroll
-    for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int mel = 16 * mt + 4 * kk + r;
-        const float pw = m[mt][r];
-        const float v = (pw > 1e-10f) ? __builtin_amdgcn_logf(pw) * 0.30102999566398120f : -10.0f;
-        tile[mel * kTileStride + wave * 16 + jl] = (v + 4.0f) * 0.25f;
-        if (frame_ok && mel < a.n_mel) {
-          wmax = fmaxf(wmax, v);
-          wmin = fminf(wmin, v);
-        }
-      }
-    wmax = wave_reduce<true>(wmax);
-    wmin = wave_reduce<false>(wmin);
-    if (lane == 0) {
-      if (wmax > -INFINITY) atomicMax(a.clip_max + b, enc_max(wmax));
-      a.block_min[((long long)b * nblk + ti.blk) * 8 + 2 * wave] = wmin;
-      a.block_min[((long long)b * nblk + ti.blk) * 8 + 2 * wave + 1] = wmin;
-    }
-    __syncthreads();
-    float* __restrict__ lo = a.out + (long long)b * a.n_mel * T + t0;
-    const int frames_here = (T - t0 < kBlockFrames) ? (T - t0) : kBlockFrames;
-    if ((T & 3) == 0 && (reinterpret_cast<uintptr_t>(lo) & 15u) == 0) {
-      constexpr int kIt = 16 * NMT / 16;                  // (16 NMT rows x 16 float4) / 256 threads
-      f32x4 row[kIt];
-#pragma unroll
-      for (int it = 0; it < kIt; ++it)
-        row[it] = *reinterpret_cast<const f32x4*>(tile + (it * 16 + (tid >> 4)) * kTileStride + 4 * (tid & 15));
-#pragma unroll
-      for (int it = 0; it < kIt; ++it) {
-        const int mel = it * 16 + (tid >> 4), c4 = tid & 15;
-        if (mel < a.n_mel && 4 * c4 < frames_here)        // T % 4 == 0: a float4 is all-valid or all-out
-          *reinterpret_cast<f32x4*>(lo + (long long)mel * T + 4 * c4) = row[it];
-      }
-    } else {
-      for (int idx = tid; idx < a.n_mel * kBlockFrames; idx += 256) {
-        const int mel = idx >> 6, fb = idx & 63;
-        if (fb < frames_here) lo[(long long)mel * T + fb] = tile[mel * kTileStride + fb];
-      }
-    }
-    if (!kTileSeparate) __syncthreads();   // the output tile overlays the twiddle slots the next tile fills
-    WFE_STAMP(5);
-  }
-}
-
-// ------------------------------------------------ kernel 1, 8-wave variant
-// Same transform, same tables, same LDS waveform image, but the 64 frames of a
-// workgroup are worked by EIGHT waves: wave = (frame group fg = wave & 3, parity
-// class cls = wave >> 2).  A wave runs only the two GEMMs of its class (cos and sin
-// sums over the even-n or the odd-n half of the folded samples): 14 accumulators
-// instead of 28, under 128 VGPRs, so FOUR waves are resident per SIMD instead of
-// two.  That is what the 4-wave kernel lacks: a wave's serial non-MFMA time
-// (staging latency, mel weights, epilogue, workgroup turnover: ~36k cycles against
-// 24.7k cycles of MFMA) cannot be covered by ONE partner wave per SIMD; three can.
-// The butterflies need both classes, so after the k-loop the two waves of a frame
-// group swap halves through LDS (class 0 keeps bin tiles 0-3, class 1 tiles 4-6),
-// each does power + a partial mel projection for its tiles, and class 1 hands its
-// partial mel sums of the mel tiles the other one finishes.  EXPERIMENTAL (WFE_K1=8 or 2):
-// correct and tested, but measured 2-9 % SLOWER than frontend_kernel, which
-// stays the default; exists for the two Whisper banks without augmentation / power output.
-#define WFE_STAMP8(i)                                                                   \
-  do {                                                                                  \
-    if (WFE_STAMPS_ON && a.stamps && lane == 0 && cls == 0) {                           \
-      unsigned long long t_;                                                            \
-      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");        \
-      a.stamps[((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + (t0 >> 6)) * 4 + ((t0 & 63) >> 4) + fg) * 8 + (i)] = t_; \
-    }                                                                                   \
-  } while (0)
-#ifdef WFE_STAMPS
-constexpr bool WFE_STAMPS_ON = true;
-#else
-constexpr bool WFE_STAMPS_ON = false;
-#endif
-
-// FG = frame groups (of 16 frames) per workgroup: the workgroup has 2 FG waves and
-// covers 16 FG frames.  FG = 2 (4 waves, 32 frames, 38 KB of LDS) puts FOUR
-// workgroups on a CU, one wave of each on every SIMD: four independent phase
-// streams per SIMD (waves of one workgroup are phase-locked by its barriers, so
-// FG = 4 -- two workgroups of 8 waves -- has only two).
-template <int NMT, int BANK, int FG>
-__global__ __launch_bounds__(128 * FG, 4) void frontend8_kernel(const FrontArgs a) {
-  static_assert(BANK == 1 || BANK == 2, "compile-time mel masks only");
-  static_assert(FG == 2 || FG == 4, "2 or 4 frame groups");
-  constexpr int NT = 128 * FG;                                     // threads
-  constexpr int BF = 16 * FG;                                      // frames per workgroup
-  constexpr int BS = BF * kHop + (kNfft - kHop);                   // padded-signal positions they cover
-  constexpr int kWave = (BS + BS / kHop + 4) / 4 * 4;              // LDS image: position q at q + q / 160
-  constexpr int TW = 512 / NT;                                     // twiddle float4 per thread and k-step
-  constexpr int kXFloats = FG * 3584;                              // class exchange
-  constexpr int kYFloats = FG * NMT * 256;                         // partial mel sums of class 1
-  constexpr int kLoop = kWave + 2 * kDftStepFloats;                // waveform image + 2 twiddle slots
-  // Y behind X when that still leaves 4 (FG = 2) / 2 (FG = 4) workgroups per CU: saves a barrier
-  constexpr bool kYSeparate = kXFloats + kYFloats <= (FG == 2 ? 9984 : 20224);
-  constexpr int kPost = kYSeparate ? kXFloats + kYFloats : (kXFloats > kYFloats ? kXFloats : kYFloats);
-  constexpr int kLds = kLoop > kPost ? kLoop : kPost;
-  constexpr int kOwn0 = (NMT + 1) / 2;                             // mel tiles finished by class 0; class 1: the rest
-  __shared__ __attribute__((aligned(16))) float lds[kLds];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int fg = wave & (FG - 1), cls = wave / FG;
-  const int b = blockIdx.y;
-  const int t0 = blockIdx.x * BF;
-  const int n = a.n_samples;
-  const int T = a.n_frames;
-  const int nblk = (T + kBlockFrames - 1) / kBlockFrames;
-  const Source src = make_source(a, b);
-  const float* __restrict__ w = src.w;
-  int len = a.lengths[b];
-  if (len < 0) len = 0;
-  if (len > n) len = n;                         // truncation=True (HF:300-307)
-  WFE_STAMP8(0);
-  const int p0 = t0 * kHop;
-  const int i_first = p0 - kHalf;
-  {                                             // silent workgroup: see frontend_kernel
-    const int i_last = i_first + BS - 1;
-    if (i_first >= len && (i_last < n || 2 * (n - 1) - i_last >= len)) {
-      if (tid == 0) atomicMax(a.clip_max + b, enc_max(-10.0f));
-      if (tid < 2 * FG) a.block_min[(((long long)b * nblk + (t0 >> 6)) * 4 + ((t0 & 63) >> 4)) * 2 + tid] = -INFINITY;
-      return;
-    }
-  }
-  auto stagger = [&]() {                        // see frontend_kernel
-    if (tid == 0) {
-      const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-      const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
-      const unsigned key = ((xcc & 15u) << 8) | ((hw >> 8) & 255u);
-      lds[0] = __uint_as_float(atomicAdd(a.cu_tickets + key, 1u));
-    }
-    __syncthreads();
-    const unsigned ticket = __float_as_uint(lds[0]);
-    __syncthreads();
-    // the workgroups that start together on a CU (2 or 4) are spread over one lifetime
-    const unsigned first_round = 8 / FG;
-    if (ticket > 0u && ticket < first_round)
-      for (unsigned i = 0; i < ticket * (FG == 2 ? 2u : 3u); ++i) __builtin_amdgcn_s_sleep(127);
-  };
-
-  // twiddles of k-steps 0, 1 (-> the two LDS slots) and 2 (staging register): one float4 per thread and step
-  const f32x4* __restrict__ gtab = reinterpret_cast<const f32x4*>(a.dft_tab) + tid;
-  f32x4* const slots = reinterpret_cast<f32x4*>(lds + kWave);                // 2 x 512 float4
-  // Three staging sets: the twiddles of step s+4 are requested in step s and parked in
-  // LDS in step s+2 -- two whole steps for the L2 round trip (a step of this kernel is
-  // short: 14 MFMAs).  Set s % 3 receives in step s, set (s + 1) % 3 is written out.
-  f32x4 g0[TW], g1[TW], G[3][TW];
-#pragma unroll
-  for (int i = 0; i < TW; ++i) {
-    g0[i] = gtab[NT * i];
-    g1[i] = gtab[512 + NT * i];
-    G[1][i] = gtab[1024 + NT * i];          // A(2), written out in step 0
-    G[2][i] = gtab[1536 + NT * i];          // A(3), written out in step 1
-    G[0][i] = G[1][i];
-  }
-
-  // ---- stage the padded-signal span [160 t0, 160 t0 + 10480) into LDS
-  {
-    const bool inside = i_first >= 0 && i_first + BS <= len;
-    const bool interior = inside && w && ((reinterpret_cast<uintptr_t>(w + i_first) & 15u) == 0);
-    const bool interior16 = inside && src.pcm && src.ch == 1 &&
-                            ((reinterpret_cast<uintptr_t>(src.pcm + i_first) & 15u) == 0);
-    if (interior16) {
-      using i32x4 = __attribute__((ext_vector_type(4))) int;
-      const i32x4* __restrict__ src8 = reinterpret_cast<const i32x4*>(src.pcm + i_first);
-      constexpr int kVec = BS / 8;
-      constexpr int kIters = (kVec + NT - 1) / NT;
-      i32x4 buf[kIters];
-#pragma unroll
-      for (int it = 0; it < kIters; ++it) {
-        const int v8 = tid + NT * it;
-        if (v8 < kVec) buf[it] = src8[v8];
-      }
-      stagger();
-      constexpr float kScale = 1.0f / 32768.0f;
-#pragma unroll
-      for (int it = 0; it < kIters; ++it) {
-        const int v8 = tid + NT * it;
-        if (v8 < kVec) {
-          const int q = 8 * v8;
-          const int base = q + q / kHop;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const int pair = buf[it][j];
-            lds[base + 2 * j + 0] = (float)(short)(pair & 0xffff) * kScale;
-            lds[base + 2 * j + 1] = (float)(pair >> 16) * kScale;
-          }
-        }
-      }
-    } else if (interior) {
-      const f32x4* __restrict__ src4 = reinterpret_cast<const f32x4*>(w + i_first);
-      constexpr int kIters = (BS / 4 + NT - 1) / NT;
-      f32x4 buf[kIters];
-#pragma unroll
-      for (int it = 0; it < kIters; ++it) {
-        const int v4 = tid + NT * it;
-        if (v4 < BS / 4) buf[it] = (WFE_EXP & 256) ? f32x4{0.1f, 0.2f, -0.1f, 0.3f} : src4[v4];
-      }
-      stagger();
-#pragma unroll
-      for (int it = 0; it < kIters; ++it) {
-        const int v4 = tid + NT * it;
-        if (v4 < BS / 4) {
-          const int q = 4 * v4;
-          const int base = q + q / kHop;
-          lds[base + 0] = buf[it][0];
-          lds[base + 1] = buf[it][1];
-          lds[base + 2] = buf[it][2];
-          lds[base + 3] = buf[it][3];
-        }
-      }
-    } else {
-      stagger();
-      constexpr int kBatch = 7;
-      for (int q0 = tid; q0 < BS; q0 += NT * kBatch) {
-        float vals[kBatch];
-#pragma unroll
-        for (int u = 0; u < kBatch; ++u) {
-          const int q = q0 + NT * u;
-          int i = p0 + q - kHalf;
-          if (i < 0) i = -i;                    // reflect
-          if (i >= n) i = 2 * (n - 1) - i;
-          float v = 0.f;
-          if (q < BS && i >= 0 && i < len) v = src.at(i);
-          vals[u] = v;
-        }
-#pragma unroll
-        for (int u = 0; u < kBatch; ++u) {
-          const int q = q0 + NT * u;
-          if (q < BS) lds[pad_q(q)] = vals[u];
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < TW; ++i) {
-    slots[NT * i + tid] = g0[i];
-    slots[512 + NT * i + tid] = g1[i];
-  }
-  WFE_STAMP8(1);
-  __syncthreads();
-  WFE_STAMP8(2);
-
-  // ---- this wave's two GEMMs (cos . e and sin . o over its parity class)
-  const int jl = lane & 15;
-  const int kk = lane >> 4;
-  const int d_lo = 2 * (kk >> 1) + 16 * (kk & 1);
-  const int d_hi = 2 * kk;
-  const int rowbase = 161 * (fg * 16 + jl);
-  const int c0 = cls ? 1 : 2;
-  f32x4 acc[2][7];
-#pragma unroll
-  for (int g = 0; g < 2; ++g)
-#pragma unroll
-    for (int bt = 0; bt < 7; ++bt) acc[g][bt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float xf = 0.f, xb = 0.f;
-  auto sample_request = [&](int s, int backward) {
-    const bool tail = s == kSteps - 1;
-    const int nb = tail ? 192 : (32 * (s >> 2) + 4 * (s & 3));
-    const int dl = tail ? d_hi : d_lo;
-    const int nn = nb + dl + c0;                       // 1..200
-    if (backward) xb = lds[rowbase - dl + kNfft - nb - c0 + 1 + ((kNfft - nn) >= 2 * kHop ? 1 : 0)];
-    else xf = lds[rowbase + dl + nb + c0 + (nn >= kHop ? 1 : 0)];
-  };
-  const int gbase = 2 * cls * 128 + lane;              // float4 index of this class's first GEMM in a slot
-  Frag7 Ra[2], Rb[2];
-#pragma unroll
-  for (int g = 0; g < 2; ++g) Ra[g] = load_frag7(slots + gbase + g * 128);
-  sample_request(0, 0);
-  sample_request(0, 1);
-  __syncthreads();      // slot 0 is overwritten in the middle of step 0
-#pragma unroll
-  for (int s = 0; s < kSteps; ++s) {
-    Frag7(&Rc)[2] = (s & 1) ? Rb : Ra;
-    Frag7(&Rn)[2] = (s & 1) ? Ra : Rb;
-    const bool next = s + 1 < kSteps, stage = s + 2 < kSteps;
-    const f32x4* nslot = slots + ((s + 1) & 1) * 512 + gbase;
-    const float e = xf + xb, o = xf - xb;
-    f32x4(&Gw)[TW] = G[(s + 1) % 3];        // holds A(s+2), requested in step s-2
-    f32x4(&Gr)[TW] = G[s % 3];              // receives A(s+4)
-    constexpr int kReq = 2 * TW + 6;        // requests of a step, one behind each of its first MFMAs
-    auto request = [&](int i) {
-      if (i < TW) {
-        if (s + 4 < kSteps) Gr[i] = reinterpret_cast<const f32x4*>(a.dft_tab)[(s + 4) * 512 + NT * i + (unsigned)tid];
-      } else if (i < 2 * TW) {
-        if (stage) slots[(s & 1) * 512 + NT * (i - TW) + tid] = Gw[i - TW];
-      } else if (i < 2 * TW + 4) {
-        const int g = (i - 2 * TW) >> 1;
-        if (next) {
-          if ((i - 2 * TW) & 1) Rn[g].hi = *reinterpret_cast<const f32x3*>(nslot + g * 128 + 64);
-          else Rn[g].lo = nslot[g * 128];
-        }
-      } else if (next) {
-        sample_request(s + 1, i - (2 * TW + 4));
-      }
-    };
-#pragma unroll
-    for (int m = 0; m < 14; ++m) {
-      acc[m / 7][m % 7] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rc[m / 7].at(m % 7), (m / 7) ? o : e, acc[m / 7][m % 7], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (m < kReq) {
-        request(m);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    if (next) __syncthreads();
-  }
-  WFE_STAMP8(3);
-
-  // ---- mel weights of this wave's bin tiles (class 0: tiles 0-3, class 1: tiles 4-6), one batch
-  const f32x4* __restrict__ mtab = reinterpret_cast<const f32x4*>(a.mel_tab) + lane;
-  auto live = [](int f, int bt, int mt) {
-    return (((BANK == 1 ? kMelMask80[f * 7 + bt] : kMelMask128[f * 7 + bt]) >> mt) & 1u) != 0;
-  };
-  f32x4 m[NMT];
-#pragma unroll
-  for (int mt = 0; mt < NMT; ++mt) m[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float* const xfg = lds + fg * 3584;                  // [A->B: 2 x 3 tiles | B->A: 2 x 4 tiles] x 4 regs x 64 lanes
-  __syncthreads();                                     // every wave is out of the k-loop: the image and the slots are dead
-
-  if (cls == 0) {
-    f32x4 wv[2][4][NMT];
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-      for (int bt = 0; bt < 4; ++bt)
-#pragma unroll
-        for (int mt = 0; mt < NMT; ++mt)
-          if (live(f, bt, mt)) wv[f][bt][mt] = mtab[((f * 7 + bt) * kMelTiles + mt) * 64];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int bt = 4; bt < 7; ++bt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xfg[((g * 3 + (bt - 4)) * 4 + r) * 64 + lane] = acc[g][bt][r];
-    __syncthreads();
-#pragma unroll
-    for (int bt = 0; bt < 4; ++bt) {
-      f32x4 co, so;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        co[r] = xfg[1536 + ((0 * 4 + bt) * 4 + r) * 64 + lane];
-        so[r] = xfg[1536 + ((1 * 4 + bt) * 4 + r) * 64 + lane];
-      }
-      const f32x4 ce = acc[0][bt], se = acc[1][bt];
-      const f32x4 rp = ce + co, ip = se + so, rm = ce - co, im = se - so;
-      const f32x4 P0 = rp * rp + ip * ip, P1 = rm * rm + im * im;
-#pragma unroll
-      for (int mt = 0; mt < NMT; ++mt) {
-        if (live(0, bt, mt)) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) m[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0][bt][mt][r], P0[r], m[mt], 0, 0, 0);
-        }
-        if (live(1, bt, mt)) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) m[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1][bt][mt][r], P1[r], m[mt], 0, 0, 0);
-        }
-      }
-    }
-  } else {
-    f32x4 wv[2][3][NMT];
-#pragma unroll
-    for (int f = 0; f < 2; ++f)
-#pragma unroll
-      for (int bt = 4; bt < 7; ++bt)
-#pragma unroll
-        for (int mt = 0; mt < NMT; ++mt)
-          if (live(f, bt, mt)) wv[f][bt - 4][mt] = mtab[((f * 7 + bt) * kMelTiles + mt) * 64];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-      for (int bt = 0; bt < 4; ++bt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xfg[1536 + ((g * 4 + bt) * 4 + r) * 64 + lane] = acc[g][bt][r];
-    __syncthreads();
-#pragma unroll
-    for (int bt = 4; bt < 7; ++bt) {
-      f32x4 ce, se;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        ce[r] = xfg[((0 * 3 + (bt - 4)) * 4 + r) * 64 + lane];
-        se[r] = xfg[((1 * 3 + (bt - 4)) * 4 + r) * 64 + lane];
-      }
-      const f32x4 co = acc[0][bt], so = acc[1][bt];
-      const f32x4 rp = ce + co, ip = se + so, rm = ce - co, im = se - so;
-      const f32x4 P0 = rp * rp + ip * ip, P1 = rm * rm + im * im;
-#pragma unroll
-      for (int mt = 0; mt < NMT; ++mt) {
-        if (live(0, bt, mt)) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) m[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[0][bt - 4][mt][r], P0[r], m[mt], 0, 0, 0);
-        }
-        if (live(1, bt, mt)) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) m[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[1][bt - 4][mt][r], P1[r], m[mt], 0, 0, 0);
-        }
-      }
-    }
-  }
-  WFE_STAMP8(4);
-  if (WFE_EXP & 1024) return;                          // diagnostic: no epilogue at all
-  // ---- each wave of the pair hands over its partial mel sums of the tiles the OTHER one
-  // finishes, then finishes its own: log10 (exact -10 at the floor, HF:159), (v + 4) / 4
-  // (the clamp of kernel 2 commutes with it), utterance max, minimum, and straight to
-  // HBM -- 16 frames of a mel row are one 64-byte run; no transposition, no further barrier.
-  if (!kYSeparate) __syncthreads();                    // Y overlays the exchange area: wait until it is read out
-  float* const ysum = lds + (kYSeparate ? kXFloats : 0) + fg * (NMT * 256);
-  if (cls == 0) {
-#pragma unroll
-    for (int mt = kOwn0; mt < NMT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ysum[(mt * 4 + r) * 64 + lane] = m[mt][r];
-  } else {
-#pragma unroll
-    for (int mt = 0; mt < kOwn0; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ysum[(mt * 4 + r) * 64 + lane] = m[mt][r];
-  }
-  __syncthreads();
-  const int frame = t0 + fg * 16 + jl;
-  const bool frame_ok = frame < T;
-  float* __restrict__ lo = a.out + (long long)b * a.n_mel * T + frame;
-  float wmax = -INFINITY, wmin = INFINITY;
-  auto finish = [&](int mt) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int mel = 16 * mt + 4 * kk + r;
-      const float pw = m[mt][r] + ysum[(mt * 4 + r) * 64 + lane];
-      const float v = (pw > 1e-10f) ? __builtin_amdgcn_logf(pw) * 0.30102999566398120f : -10.0f;
-      if (frame_ok && mel < a.n_mel) {
-        lo[(long long)mel * T] = (v + 4.0f) * 0.25f;
-        wmax = fmaxf(wmax, v);
-        wmin = fminf(wmin, v);
-      }
-    }
-  };
-  if (cls == 0) {
-#pragma unroll
-    for (int mt = 0; mt < kOwn0; ++mt) finish(mt);
-  } else {
-#pragma unroll
-    for (int mt = kOwn0; mt < NMT; ++mt) finish(mt);
-  }
-  if (WFE_EXP & 512) return;
-  wmax = wave_reduce<true>(wmax);
-  wmin = wave_reduce<false>(wmin);
-  if (lane == 0) {
-    if (wmax > -INFINITY) atomicMax(a.clip_max + b, enc_max(wmax));
-    a.block_min[(((long long)b * nblk + (t0 >> 6)) * 4 + ((t0 & 63) >> 4) + fg) * 2 + cls] = wmin;
-  }
-  WFE_STAMP8(5);
-}
-
 // ------------------------------------------------------------- kernel 2
 // log_spec = maximum(log_spec, max - 8.0); (log_spec + 4.0) / 4.0   (HF:160-165).
 // Kernel 1 already stored g(v) = (v + 4) / 4 and the minimum v of each of its
@@ -1797,7 +919,7 @@ __global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ out, con
   const int b = blockIdx.y;
   const float floor_v = dec_max(clip_max[b]) - 8.0f;
   const float* bm = block_min + ((long long)b * gridDim.x + blockIdx.x) * 8;   // [frame group 4][wave of the pair 2]
-  // decided per half tile (32 frames): the 32-frame variant of kernel 1 marks silence per half
+  // decided per half tile (32 frames): two frame groups, each with the minima of its (up to two) waves
   const int tid = threadIdx.x;
   const float floor_g = (floor_v + 4.0f) * 0.25f;
   float* __restrict__ p = out + (long long)b * n_mel * T + blockIdx.x * kBlockFrames;
@@ -2183,30 +1305,7 @@ static hipError_t launch_k1(const FrontArgs& a, int batch, hipStream_t stream) {
 
 // bank: 1 = the 80-mel Whisper bank, 2 = the 128-mel bank (compile-time block
 // masks), 0 = any other feature_size (run-time masks).
-template <int NMT, int BANK>
-static hipError_t launch_k1p(const FrontArgs& a, int batch, hipStream_t stream) {
-  const long long n_tiles = (long long)batch * ((a.n_frames + kBlockFrames - 1) / kBlockFrames);
-  long long grid = 2LL * (a.cu_count > 0 ? a.cu_count : 256);       // two resident workgroups per CU
-  if (grid > n_tiles) grid = n_tiles;
-  hipLaunchKernelGGL((frontendp_kernel<NMT, BANK>), dim3((unsigned)grid), dim3(256), 0, stream, a, (int)n_tiles);
-  return hipGetLastError();
-}
-
-template <int NMT, int BANK, int FG>
-static hipError_t launch_k1x8(const FrontArgs& a, int batch, hipStream_t stream) {
-  const dim3 grid((a.n_frames + 16 * FG - 1) / (16 * FG), batch);
-  hipLaunchKernelGGL((frontend8_kernel<NMT, BANK, FG>), grid, dim3(128 * FG), 0, stream, a);
-  return hipGetLastError();
-}
-
-hipError_t launch_frontend(const FrontArgs& a, int batch, int mode, bool aug, int bank, hipStream_t stream,
-                           int variant) {
-  if (mode == 0 && !aug && variant == 1 && bank == 1) return launch_k1p<5, 1>(a, batch, stream);
-  if (mode == 0 && !aug && variant == 1 && bank == 2) return launch_k1p<8, 2>(a, batch, stream);
-  if (mode == 0 && !aug && variant == 2 && bank == 1) return launch_k1x8<5, 1, 2>(a, batch, stream);
-  if (mode == 0 && !aug && variant == 2 && bank == 2) return launch_k1x8<8, 2, 2>(a, batch, stream);
-  if (mode == 0 && !aug && variant == 8 && bank == 1) return launch_k1x8<5, 1, 4>(a, batch, stream);
-  if (mode == 0 && !aug && variant == 8 && bank == 2) return launch_k1x8<8, 2, 4>(a, batch, stream);
+hipError_t launch_frontend(const FrontArgs& a, int batch, int mode, bool aug, int bank, hipStream_t stream) {
   if (mode == 1)
     return aug ? launch_k1<5, true, true, 0>(a, batch, stream) : launch_k1<5, true, false, 0>(a, batch, stream);
   if (bank == 1)
