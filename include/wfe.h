@@ -12,7 +12,13 @@
  * failure, never throws, never takes ownership of caller buffers, and is
  * stream-ordered (asynchronous) with respect to `stream` (a hipStream_t passed
  * as void*; NULL = the null stream).  Device pointers must belong to the
- * handle's device.  One host thread per handle at a time.
+ * handle's device.  One host thread per handle at a time.  A handle owns small
+ * device workspaces (utterance maxima, tile minima, resolved gains, filter
+ * tables) that every call reuses: calls on ONE handle must be ordered -- issue
+ * them on one stream, or order the streams with events; use one handle per
+ * stream for concurrent launches.  Workspaces grow on demand (hipMalloc /
+ * hipFree, which synchronise the device); after the first call at a given batch
+ * shape the hot path allocates nothing.
  */
 #ifndef WFE_H
 #define WFE_H
