@@ -151,7 +151,7 @@ int ensure_aug_workspace(wfe_context* h, size_t total_ops, const float* noise, c
       h->noise_cap = 0;
       h->noise_seen = nullptr;
       size_t cap = (size_t)n_noise < 64 ? 64 : (size_t)n_noise * 2;
-      HIP_TRY(h, hipMalloc(&h->d_noise_meansq, cap * sizeof(double)));
+      HIP_TRY(h, hipMalloc(&h->d_noise_meansq, cap * wfe::kNoiseParts * sizeof(double)));
       h->noise_cap = cap;
     }
     // The mean squares are recomputed on every call: the bank may have been

@@ -40,7 +40,7 @@ struct FrontArgs {
   const int* op_begin;
   const float* noise;
   const long long* noise_off;
-  const double* noise_meansq;    // (n_noise) mean square of each noise clip
+  const double* noise_meansq;    // (n_noise x kNoiseParts) partial sums of squares of each noise clip
   Resolved* resolved;            // (total ops) filled by the reduce kernel
   unsigned long long* stamps;    // diagnostic builds (-DWFE_STAMPS) only: 8 clock stamps per wave
 };
@@ -50,7 +50,8 @@ hipError_t launch_frontend(const FrontArgs& a, int batch, int mode, bool augment
 // max(stored, g(max-8)) over the tiles whose minimum is below max-8 (kernel 1 stored g(v) = (v+4)/4)
 hipError_t launch_clamp(float* out, const unsigned* clip_max, const float* block_min, int batch, int n_mel,
                         int n_frames, hipStream_t stream);
-// mean squares of the noise clips (once per noise bank)
+// partial sums of squares of the noise clips: meansq has n_noise x kNoiseParts doubles
+constexpr int kNoiseParts = 16;
 hipError_t launch_noise_meansq(const float* noise, const long long* noise_off, int n_noise, double* meansq,
                                hipStream_t stream);
 // resolve the data-dependent scalars of every utterance's chain (NOISE gains, AFFINE stats)

@@ -973,19 +973,30 @@ __device__ inline double block_sum(double v, double* sh) {
   return t;
 }
 
-__global__ __launch_bounds__(1024) void noise_meansq_kernel(const float* __restrict__ noise,
-                                                            const long long* __restrict__ off,
-                                                            double* __restrict__ meansq) {
-  __shared__ double sh[16];
-  const int j = blockIdx.x;
+// Mean square of every noise clip: kNoiseParts workgroups per clip over a fixed
+// partition write float64 partial sums of the float32 squares; noise_meansq() combines
+// them in index order (scheduling cannot change the result).
+__global__ __launch_bounds__(256) void noise_meansq_kernel(const float* __restrict__ noise,
+                                                           const long long* __restrict__ off,
+                                                           double* __restrict__ partial) {
+  __shared__ double sh[4];
+  const int j = blockIdx.y, part = blockIdx.x;
   const long long o0 = off[j], ln = off[j + 1] - o0;
+  const long long per = (ln + kNoiseParts - 1) / kNoiseParts;
+  const long long lo = part * per, hi = (lo + per < ln) ? lo + per : ln;
   double s = 0.0;
-  for (long long i = threadIdx.x; i < ln; i += 1024) {
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) {
     const float x = noise[o0 + i];
     s += (double)__fmul_rn(x, x);                    // float32 squares, as sample ** 2
   }
-  s = block_sum<1024>(s, sh);
-  if (threadIdx.x == 0) meansq[j] = ln > 0 ? s / (double)ln : 0.0;
+  s = block_sum<256>(s, sh);
+  if (threadIdx.x == 0) partial[(long long)j * kNoiseParts + part] = s;
+}
+__device__ inline double noise_meansq(const FrontArgs& a, int j) {
+  const long long ln = a.noise_off[j + 1] - a.noise_off[j];
+  double s = 0.0;
+  for (int p = 0; p < kNoiseParts; ++p) s += a.noise_meansq[(long long)j * kNoiseParts + p];
+  return ln > 0 ? s / (double)ln : 0.0;
 }
 
 // rms_db (utils/reader.py:350-353) under NumPy-2 float32 scalar semantics
@@ -1055,8 +1066,8 @@ __global__ __launch_bounds__(256) void resolve_partial_kernel(const FrontArgs a,
 // ENTERING it, so earlier ops -- including earlier resolved ones -- are applied.
 // The first such op takes its sums from resolve_partial_kernel; any later one is
 // summed here.
-__global__ __launch_bounds__(1024) void resolve_kernel(const FrontArgs a, const double* __restrict__ partials) {
-  __shared__ double sh[16];
+__global__ __launch_bounds__(256) void resolve_kernel(const FrontArgs a, const double* __restrict__ partials) {
+  __shared__ double sh[4];
   const int b = blockIdx.x;
   const Source src = make_source(a, b);
   int raw_len = a.lengths[b];
@@ -1076,13 +1087,13 @@ __global__ __launch_bounds__(1024) void resolve_kernel(const FrontArgs a, const 
         s2 += partials[((long long)b * kResolveParts + p) * 2 + 1];
       }
     } else {
-      for (int i = threadIdx.x; i < L; i += 1024) {
+      for (int i = threadIdx.x; i < L; i += 256) {
         const float x = chain_eval(c, k, i);
         s1 += (double)x;
         s2 += (double)__fmul_rn(x, x);
       }
-      s1 = block_sum<1024>(s1, sh);
-      s2 = block_sum<1024>(s2, sh);
+      s1 = block_sum<256>(s1, sh);
+      s2 = block_sum<256>(s2, sh);
     }
     first = false;
     if (threadIdx.x == 0) {
@@ -1092,7 +1103,7 @@ __global__ __launch_bounds__(1024) void resolve_kernel(const FrontArgs a, const 
         const float gain = fminf(300.0f, __fsub_rn(-20.0f, rms_db_f32(ms)));
         const float g1 = powf(10.0f, __fdiv_rn(gain, 20.0f));
         const float s_db = rms_db_f32(ms * (double)g1 * (double)g1);
-        const float n_db = rms_db_f32(a.noise_meansq[c.ops[k].i0]);
+        const float n_db = rms_db_f32(noise_meansq(a, c.ops[k].i0));
         const float ng = fminf(__fsub_rn(__fsub_rn(s_db, n_db), (float)c.ops[k].i2), 300.0f);
         r.a = g1;
         r.b = powf(10.0f, __fdiv_rn(ng, 20.0f));
@@ -1327,7 +1338,7 @@ hipError_t launch_clamp(float* out, const unsigned* clip_max, const float* block
 hipError_t launch_noise_meansq(const float* noise, const long long* off, int n_noise, double* meansq,
                                hipStream_t stream) {
   if (n_noise <= 0) return hipSuccess;
-  hipLaunchKernelGGL(noise_meansq_kernel, dim3(n_noise), dim3(1024), 0, stream, noise, off, meansq);
+  hipLaunchKernelGGL(noise_meansq_kernel, dim3(kNoiseParts, n_noise), dim3(256), 0, stream, noise, off, meansq);
   return hipGetLastError();
 }
 
@@ -1335,7 +1346,7 @@ hipError_t launch_resolve(const FrontArgs& a, int batch, double* partials, hipSt
   hipLaunchKernelGGL(resolve_partial_kernel, dim3(kResolveParts, batch), dim3(256), 0, stream, a, partials);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(resolve_kernel, dim3(batch), dim3(1024), 0, stream, a, partials);
+  hipLaunchKernelGGL(resolve_kernel, dim3(batch), dim3(256), 0, stream, a, partials);
   return hipGetLastError();
 }
 
