@@ -26,11 +26,27 @@ blocks = B * 47
 stamps = torch.zeros((blocks * 4, 8), dtype=torch.int64, device="cuda")
 wav = 0.1 * torch.randn((B, 480000), device="cuda")
 lens = torch.full((B,), 480000, dtype=torch.int32, device="cuda")
+run = lambda: fe.logmel(wav, lens)                                   # noqa: E731
+if os.environ.get("WFE_PHASE_AUG") == "1":                           # BASELINE config 3 chain (see bench.py --augment)
+    import random
+    from wfe_amd.augment import AugmentPlanner
+    from wfe_amd.frontend import NoiseBank
+    bank = [(0.05 * np.random.default_rng(9000 + j).standard_normal(160000)).astype(np.float32) for j in range(16)]
+    planner = AugmentPlanner([
+        {"type": "noise", "prob": 1.0, "params": {"min_snr_dB": 10, "max_snr_dB": 50}},
+        {"type": "speed", "prob": 1.0, "params": {"min_speed_rate": 0.9, "max_speed_rate": 1.1, "num_rates": 3}},
+        {"type": "shift", "prob": 1.0, "params": {"min_shift_ms": -5, "max_shift_ms": 5}},
+        {"type": "volume", "prob": 1.0, "params": {"min_gain_dBFS": -15, "max_gain_dBFS": 15}},
+    ], noise_lengths=[len(c) for c in bank])
+    rnd = random.Random(0)
+    packed = fe.pack_plans([planner.draw(480000, 16000, rnd)[0] for _ in range(B)])
+    nb = NoiseBank(bank, fe.device)
+    run = lambda: fe.augment_logmel(wav, lens, packed, nb)           # noqa: E731
 for _ in range(3):
-    fe.logmel(wav, lens)
+    run()
 torch.cuda.synchronize()
 assert lib.wfe_debug_stamps(fe._h, C.c_void_p(stamps.data_ptr())) == 0
-fe.logmel(wav, lens)
+run()
 torch.cuda.synchronize()
 s = stamps.cpu().numpy().astype(np.int64)
 s = s[s[:, 0] != 0]

@@ -129,7 +129,20 @@ __device__ __forceinline__ Source make_source(const FrontArgs& a, int b) {
   return s;
 }
 
+// One op of a chain with everything the per-position evaluation needs, gathered once
+// per workgroup into LDS (compile_chain): reading the descriptors, the resolved gains
+// and the noise offsets from global memory inside the staging loops costs a chain of
+// dependent scalar-load round trips per batch of positions.
+struct COp {
+  int kind, i0, i1, ln;          // ln: NOISE clip length
+  float f0, ra, rb, pad_;        // ra, rb: resolved scalars (NOISE gains / AFFINE mean, std)
+  long long o0;                  // NOISE: offset of the clip in the bank
+  double inv;                    // NOISE: 1 / ln
+};
+constexpr int kMaxCops = 16;     // longer chains are evaluated from global memory (slow, correct)
+
 struct Chain {
+  const COp* cops;               // LDS copy of the ops, or null
   const wfe_aug_op* ops;
   const Resolved* res;
   int n_ops;
@@ -145,6 +158,7 @@ struct Chain {
 __device__ inline Chain make_chain(const FrontArgs& a, int b, const Source& src, int raw_len) {
   Chain c;
   const int lo = a.op_begin[b], hi = a.op_begin[b + 1];
+  c.cops = nullptr;
   c.ops = a.ops + lo;
   c.res = a.resolved + lo;
   c.n_ops = hi - lo;
@@ -235,10 +249,45 @@ __device__ inline int chain_len(const Chain& c, int n_ops_used) {
 // identical sequence of float32 / float64 roundings.
 constexpr int kDeadIndex = -(1 << 29);       // "not a sample": out of every segment's range, |shift sums| < 2^28
 
+__device__ inline COp make_cop(const Chain& c, int k) {
+  const wfe_aug_op op = c.ops[k];
+  COp o;
+  o.kind = op.kind;
+  o.i0 = op.i0;
+  o.i1 = op.i1;
+  o.f0 = op.f0;
+  o.ln = 0;
+  o.ra = 0.f;
+  o.rb = 1.f;
+  o.pad_ = 0.f;
+  o.o0 = 0;
+  o.inv = 0.0;
+  if (op.kind == WFE_AUG_NOISE) {
+    o.o0 = c.noise_off[op.i0];
+    o.ln = (int)(c.noise_off[op.i0 + 1] - o.o0);
+    o.inv = o.ln > 0 ? 1.0 / (double)o.ln : 0.0;
+  }
+  if (op.kind == WFE_AUG_NOISE || op.kind == WFE_AUG_AFFINE) {
+    o.ra = c.res[k].a;
+    o.rb = c.res[k].b;
+  }
+  return o;
+}
+// ops [0, n_use) -> LDS, one thread per op; the caller synchronises the workgroup and
+// sets c.cops.  (n_use stops short of an op whose scalars are not resolved yet.)
+__device__ inline bool compile_chain(const Chain& c, COp* cops, int n_use, int tid) {
+  if (n_use > kMaxCops) return false;
+  if (tid < n_use) cops[tid] = make_cop(c, tid);
+  return true;
+}
+__device__ __forceinline__ COp get_cop(const Chain& c, int k) { return c.cops ? c.cops[k] : make_cop(c, k); }
+
 __device__ __forceinline__ int seg_shift_sum(const Chain& c, int lo, int hi) {
   int s = 0;
-  for (int k = lo; k < hi; ++k)
-    if (c.ops[k].kind == WFE_AUG_SHIFT) s += c.ops[k].i0;
+  for (int k = lo; k < hi; ++k) {
+    const COp op = get_cop(c, k);
+    if (op.kind == WFE_AUG_SHIFT) s += op.i0;
+  }
   return s;
 }
 
@@ -246,7 +295,7 @@ __device__ __forceinline__ int seg_shift_sum(const Chain& c, int lo, int hi) {
 template <int U>
 __device__ __forceinline__ void seg_apply(const Chain& c, int lo, int hi, int L, int (&cur)[U], float (&v)[U]) {
   for (int k = lo; k < hi; ++k) {
-    const wfe_aug_op op = c.ops[k];
+    const COp op = get_cop(c, k);
     if (op.kind == WFE_AUG_VOLUME) {
 #pragma unroll
       for (int u = 0; u < U; ++u) v[u] = __fmul_rn(v[u], op.f0);
@@ -257,32 +306,28 @@ __device__ __forceinline__ void seg_apply(const Chain& c, int lo, int hi, int L,
         cur[u] -= op.i0;
       }
     } else if (op.kind == WFE_AUG_NOISE) {
-      const Resolved r = c.res[k];
-      const long long o0 = c.noise_off[op.i0];
-      const int ln = (int)(c.noise_off[op.i0 + 1] - o0);
+      const int ln = op.ln;
       const bool wrap = ln < L;
-      const double inv = ln > 0 ? 1.0 / (double)ln : 0.0;
       float nz[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const bool in = cur[u] >= 0 && cur[u] < L && ln > 0;
         int j = cur[u] + op.i1;
         if (wrap) {                                   // cur % ln without the integer divide
-          const int qd = (int)((double)cur[u] * inv);
+          const int qd = (int)((double)cur[u] * op.inv);
           j = cur[u] - qd * ln;
           if (j < 0) j += ln;
           if (j >= ln) j -= ln;
         }
-        nz[u] = in ? c.noise[o0 + j] : 0.f;
+        nz[u] = in ? c.noise[op.o0 + j] : 0.f;
       }
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (cur[u] >= 0 && cur[u] < L && ln > 0) v[u] = __fadd_rn(__fmul_rn(v[u], r.a), __fmul_rn(nz[u], r.b));
+        if (cur[u] >= 0 && cur[u] < L && ln > 0) v[u] = __fadd_rn(__fmul_rn(v[u], op.ra), __fmul_rn(nz[u], op.rb));
     } else if (op.kind == WFE_AUG_AFFINE) {
-      const Resolved r = c.res[k];
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (cur[u] >= 0 && cur[u] < L) v[u] = __fdiv_rn(__fsub_rn(v[u], r.a), r.b);
+        if (cur[u] >= 0 && cur[u] < L) v[u] = __fdiv_rn(__fsub_rn(v[u], op.ra), op.rb);
     }
   }
 }
@@ -307,7 +352,8 @@ template <int AUXF>
 __device__ inline void stage_augmented(const Chain& c, float* __restrict__ lds, float* __restrict__ aux, int p0, int n,
                                        int len, int tid) {
   if (c.speed_at < 0) {
-    constexpr int U = 7;                        // 41 positions per thread in 6 batches of 7
+    constexpr int U = 7;                        // 41 positions per thread in 6 batches of 7 (bigger batches: no gain,
+                                                // the staging of augmented tiles is VALU-bound -- DESIGN.md)
     const int S = seg_shift_sum(c, 0, c.n_ops);
     for (int q0 = tid; q0 < kBlockSamples; q0 += 256 * U) {
       int cur[U];
@@ -461,9 +507,13 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   WFE_STAMP(0);
   Chain c;
   int len = raw_len;
+  __shared__ COp cops[AUG ? kMaxCops : 1];
   if (AUG) {
     c = make_chain(a, b, src, raw_len);
     len = chain_len(c, c.n_ops);
+    const bool compiled = compile_chain(c, cops, c.n_ops, tid);
+    __syncthreads();
+    if (compiled) c.cops = cops;
   }
   if (len > n) len = n;                         // truncation=True (HF:300-307)
   const int p0 = t0 * kHop;
@@ -1022,6 +1072,13 @@ __global__ __launch_bounds__(256) void resolve_partial_kernel(const FrontArgs a,
   const Chain c = make_chain(a, b, src, raw_len);
   const int k0 = first_resolvable(c);
   if (k0 < 0) return;
+  __shared__ COp cops[kMaxCops];
+  Chain cc = c;
+  {
+    const bool compiled = compile_chain(c, cops, k0, (int)threadIdx.x);
+    __syncthreads();
+    if (compiled) cc.cops = cops;
+  }
   int L = chain_len(c, k0);
   if (c.ops[k0].kind == WFE_AUG_AFFINE && L > a.n_samples) L = a.n_samples;
   const int per = (L + kResolveParts - 1) / kResolveParts;
@@ -1029,7 +1086,7 @@ __global__ __launch_bounds__(256) void resolve_partial_kernel(const FrontArgs a,
   double s1 = 0.0, s2 = 0.0;
   if (c.speed_at < 0 || c.speed_at >= k0) {
     constexpr int U = 8;
-    const int S = seg_shift_sum(c, 0, k0);
+    const int S = seg_shift_sum(cc, 0, k0);
     for (int i0 = lo + (int)threadIdx.x; i0 < hi; i0 += 256 * U) {
       int cur[U];
       float v[U];
@@ -1037,7 +1094,7 @@ __global__ __launch_bounds__(256) void resolve_partial_kernel(const FrontArgs a,
       for (int u = 0; u < U; ++u) cur[u] = (i0 + 256 * u < hi) ? i0 + 256 * u + S : kDeadIndex;
 #pragma unroll
       for (int u = 0; u < U; ++u) v[u] = (cur[u] >= 0 && cur[u] < c.len0) ? src.at(cur[u]) : 0.f;
-      seg_apply<U>(c, 0, k0, c.len0, cur, v);
+      seg_apply<U>(cc, 0, k0, c.len0, cur, v);
 #pragma unroll
       for (int u = 0; u < U; ++u)
         if (i0 + 256 * u < hi) {
@@ -1133,7 +1190,13 @@ __global__ __launch_bounds__(256) void waveform_kernel(const FrontArgs a, float*
   const Source src = make_source(a, b);
   int raw_len = a.lengths[b];
   if (raw_len < 0) raw_len = 0;
-  const Chain c = make_chain(a, b, src, raw_len);
+  Chain c = make_chain(a, b, src, raw_len);
+  __shared__ COp cops[kMaxCops];
+  {
+    const bool compiled = compile_chain(c, cops, c.n_ops, (int)threadIdx.x);
+    __syncthreads();
+    if (compiled) c.cops = cops;
+  }
   const int L = chain_len(c, c.n_ops);
   const int keep = L < a.n_samples ? L : a.n_samples;
   if (blockIdx.x == 0 && threadIdx.x == 0 && out_len) out_len[b] = L;
