@@ -566,7 +566,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
     __syncthreads();
     const unsigned ticket = __float_as_uint(lds[0]);
     __syncthreads();
-#if defined(WFE_STAMPS) && WFE_STAMPS == 1
+#ifdef WFE_STAMPS
     if (a.stamps && lane == 0) {
       const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
       const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
@@ -752,36 +752,27 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
       o[c] = xf[c] - xb[c];
     }
     auto mfma = [&](int g, int bt) {
-#ifdef WFE_AGPR_ACC
-      asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0"
-                   : "+a"(acc[g][bt])
-                   : "v"(Rc[g].at(bt)), "v"((g & 1) ? o[g >> 1] : e[g >> 1]));
-#else
       acc[g][bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rc[g].at(bt), (g & 1) ? o[g >> 1] : e[g >> 1], acc[g][bt],
                                                         0, 0, 0);
-#endif
     };
     f32x4(&Gw)[2] = (s & 1) ? gb : ga;      // holds A(s+2), requested during step s-1
     f32x4(&Gr)[2] = (s & 1) ? ga : gb;      // receives A(s+3)
     // the 16 requests of a step, one behind each of the first 16 MFMAs (a clump of
     // them between two MFMAs idles the matrix pipe for the clump's issue time)
-#ifndef WFE_EXP
-#define WFE_EXP 0
-#endif
     auto request = [&](int i) {
       if (i < 2) {                                          // global -> registers, A(s+3)
         // uniform base + 32-bit thread offset: a scalar-base load, no 64-bit VALU address math
-        if (s + 3 < kSteps && !(WFE_EXP & 1))
+        if (s + 3 < kSteps)
           Gr[i] = reinterpret_cast<const f32x4*>(a.dft_tab)[(s + 3) * 512 + 256 * i + (unsigned)tid];
       } else if (i < 4) {                                   // registers -> LDS, A(s+2)
-        if (stage && !(WFE_EXP & 2)) slots[(s & 1) * 512 + 256 * (i - 2) + tid] = Gw[i - 2];
+        if (stage) slots[(s & 1) * 512 + 256 * (i - 2) + tid] = Gw[i - 2];
       } else if (i < 12) {                                  // LDS -> registers, fragments of A(s+1)
         const int g = (i - 4) >> 1;
-        if (next && !(WFE_EXP & 4)) {
+        if (next) {
           if ((i - 4) & 1) Rn[g].hi = *reinterpret_cast<const f32x3*>(nslot + g * 128 + 64);
           else Rn[g].lo = nslot[g * 128];
         }
-      } else if (next && !(WFE_EXP & 8)) {                  // LDS -> registers, samples of step s+1
+      } else if (next) {                  // LDS -> registers, samples of step s+1
         sample_request(s + 1, (i - 12) >> 1, (i - 12) & 1);
       }
     };
@@ -808,7 +799,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   }
 
   WFE_STAMP(3);
-#if defined(WFE_STAMPS) && WFE_STAMPS == 1
+#ifdef WFE_STAMPS
   if (a.stamps && lane == 0)
     a.stamps[((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + blockIdx.x) * 4 + wave) * 8 + 7] = barrier_cycles;
 #endif
@@ -917,24 +908,12 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
     }
   wmax = wave_reduce<true>(wmax);
   wmin = wave_reduce<false>(wmin);
-#if defined(WFE_STAMPS) && WFE_STAMPS == 3
-  WFE_STAMP(6);
-#endif
   if (lane == 0) {
     if (wmax > -INFINITY) atomicMax(a.clip_max + b, enc_max(wmax));
     a.block_min[((long long)b * nblk + blockIdx.x) * 8 + 2 * wave] = wmin;      // both halves of the
     a.block_min[((long long)b * nblk + blockIdx.x) * 8 + 2 * wave + 1] = wmin;  // frame group's pair
   }
-#if defined(WFE_STAMPS) && WFE_STAMPS == 2
-  WFE_STAMP(6);
-#endif
-#if defined(WFE_STAMPS) && WFE_STAMPS == 3
-  WFE_STAMP(7);
-#endif
   __syncthreads();
-#if defined(WFE_STAMPS) && WFE_STAMPS == 2
-  WFE_STAMP(7);
-#endif
   float* __restrict__ lo = a.out + (long long)b * a.n_mel * T + t0;
   const int frames_here = (T - t0 < kBlockFrames) ? (T - t0) : kBlockFrames;
   if ((T & 3) == 0 && (reinterpret_cast<uintptr_t>(lo) & 15u) == 0) {
