@@ -119,6 +119,34 @@ struct Source {
     for (int cc = 0; cc < ch; ++cc) t += pcm[(long long)i * ch + cc];
     return __fdiv_rn((float)t * kScale, (float)ch);
   }
+  // v[u] = sample cur[u], 0 outside [0, L).  Branch-free: every lane loads (index clamped into
+  // the utterance) and the value is selected afterwards -- hipcc turns `in ? w[i] : 0` into a
+  // branch per element, each load in a basic block of its own with a full wait behind it, which
+  // serialises the U round trips.  The format test is outside the unrolled loop for the same reason.
+  template <int U>
+  __device__ __forceinline__ void gather(const int (&cur)[U], int L, float (&v)[U]) const {
+    constexpr float kScale = 1.0f / 32768.0f;
+    if (L <= 0) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = 0.f;
+      return;
+    }
+    int idx[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) idx[u] = min(max(cur[u], 0), L - 1);
+    if (!pcm) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = w[idx[u]];
+    } else if (ch == 1) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = (float)pcm[idx[u]] * kScale;
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = at(idx[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = (cur[u] >= 0 && cur[u] < L) ? v[u] : 0.f;
+  }
 };
 __device__ __forceinline__ Source make_source(const FrontArgs& a, int b) {
   const long long o = a.offsets ? a.offsets[b] : (long long)b * a.row_stride;
@@ -280,7 +308,8 @@ __device__ inline bool compile_chain(const Chain& c, COp* cops, int n_use, int t
   if (tid < n_use) cops[tid] = make_cop(c, tid);
   return true;
 }
-__device__ __forceinline__ COp get_cop(const Chain& c, int k) { return c.cops ? c.cops[k] : make_cop(c, k); }
+// (seg_shift_sum / seg_apply below require the compiled chain, c.cops != null)
+__device__ __forceinline__ COp get_cop(const Chain& c, int k) { return c.cops[k]; }
 
 __device__ __forceinline__ int seg_shift_sum(const Chain& c, int lo, int hi) {
   int s = 0;
@@ -311,15 +340,15 @@ __device__ __forceinline__ void seg_apply(const Chain& c, int lo, int hi, int L,
       float nz[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const bool in = cur[u] >= 0 && cur[u] < L && ln > 0;
         int j = cur[u] + op.i1;
         if (wrap) {                                   // cur % ln without the integer divide
           const int qd = (int)((double)cur[u] * op.inv);
           j = cur[u] - qd * ln;
-          if (j < 0) j += ln;
-          if (j >= ln) j -= ln;
+          j = (j < 0) ? j + ln : j;
+          j = (j >= ln) ? j - ln : j;
         }
-        nz[u] = in ? c.noise[op.o0 + j] : 0.f;
+        j = min(max(j, 0), ln > 0 ? ln - 1 : 0);       // branch-free gather (see Source::gather); unused
+        nz[u] = ln > 0 ? c.noise[op.o0 + j] : 0.f;     // lanes read a valid sample and drop it below
       }
 #pragma unroll
       for (int u = 0; u < U; ++u)
@@ -351,9 +380,18 @@ __device__ __forceinline__ double speed_pos(const Chain& c, int i) {
 template <int AUXF>
 __device__ inline void stage_augmented(const Chain& c, float* __restrict__ lds, float* __restrict__ aux, int p0, int n,
                                        int len, int tid) {
+  if (!c.cops) {                                // more than kMaxCops ops: per-position evaluation from global memory
+    for (int q = tid; q < kBlockSamples; q += 256) {
+      const int i = padded_index(q, p0, n, len);
+      lds[pad_q(q)] = i >= 0 ? chain_eval(c, c.n_ops, i) : 0.f;
+    }
+    return;
+  }
   if (c.speed_at < 0) {
-    constexpr int U = 7;                        // 41 positions per thread in 6 batches of 7 (bigger batches: no gain,
-                                                // the staging of augmented tiles is VALU-bound -- DESIGN.md)
+    // 41 positions per thread in 2 batches of 21: each batch pays one HBM round trip for the raw
+    // samples and one gather round trip per NOISE op (~3k cycles each under load), so few, large
+    // batches -- possible since the gathers are branch-free
+    constexpr int U = 21;
     const int S = seg_shift_sum(c, 0, c.n_ops);
     for (int q0 = tid; q0 < kBlockSamples; q0 += 256 * U) {
       int cur[U];
@@ -365,8 +403,7 @@ __device__ inline void stage_augmented(const Chain& c, float* __restrict__ lds, 
         ok[u] = i >= 0;
         cur[u] = ok[u] ? i + S : kDeadIndex;
       }
-#pragma unroll
-      for (int u = 0; u < U; ++u) v[u] = (cur[u] >= 0 && cur[u] < c.len0) ? c.src.at(cur[u]) : 0.f;
+      c.src.gather<U>(cur, c.len0, v);
       seg_apply<U>(c, 0, c.n_ops, c.len0, cur, v);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -377,7 +414,7 @@ __device__ inline void stage_augmented(const Chain& c, float* __restrict__ lds, 
     return;
   }
 
-  constexpr int U = 6;
+  constexpr int U = 11;                         // <= 22 positions per thread and pass: 2 batches (see above)
   const int S0 = seg_shift_sum(c, 0, c.speed_at);
   const int S1 = seg_shift_sum(c, c.speed_at + 1, c.n_ops);
   const int last = c.len0 - 1;
@@ -432,8 +469,7 @@ __device__ inline void stage_augmented(const Chain& c, float* __restrict__ lds, 
         float v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) cur[u] = (j0 + 256 * u <= jhi) ? j0 + 256 * u + S0 : kDeadIndex;
-#pragma unroll
-        for (int u = 0; u < U; ++u) v[u] = (cur[u] >= 0 && cur[u] < c.len0) ? c.src.at(cur[u]) : 0.f;
+        c.src.gather<U>(cur, c.len0, v);
         seg_apply<U>(c, 0, c.speed_at, c.len0, cur, v);
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -441,7 +477,17 @@ __device__ inline void stage_augmented(const Chain& c, float* __restrict__ lds, 
       }
     }
     __syncthreads();
-    // pass B: np.interp in float64 between two buffered seg0 values, then seg1
+    if (!buffered) {
+      // span too wide for the buffer (speed rate > ~20): per-position evaluation of the whole chain
+      for (int q = qa + tid; q < qb; q += 256) {
+        const int i = padded_index(q, p0, n, len);
+        lds[pad_q(q)] = i >= 0 ? chain_eval(c, c.n_ops, i) : 0.f;
+      }
+      __syncthreads();
+      continue;
+    }
+    // pass B: np.interp in float64 between two buffered seg0 values, then seg1.  Branch-free
+    // per element (selects, clamped LDS indices): the U elements stay in one basic block.
     for (int q0 = qa + tid; q0 < qb; q0 += 256 * U) {
       int cur[U];
       float v[U];
@@ -452,27 +498,19 @@ __device__ inline void stage_augmented(const Chain& c, float* __restrict__ lds, 
         const int i = (q < qb) ? padded_index(q, p0, n, len) : -1;
         ok[u] = i >= 0;
         cur[u] = ok[u] ? i + S1 : kDeadIndex;
-        float x = 0.f;
-        if (cur[u] >= 0 && cur[u] < c.len1) {
-          if (buffered) {
-            const double pos = speed_pos(c, cur[u]);
-            // (indices are inside [jlo, jhi] by construction; the clamps keep a
-            // mistake in the hull above a wrong value instead of a stray LDS access)
-            auto at = [&](int j) { return aux[min(max(j - jlo, 0), AUXF - 1)]; };
-            if (pos >= (double)last) {
-              x = at(last);
-            } else {
-              const int j = (int)pos;
-              const double a0 = (double)at(j);
-              const double fr = pos - (double)j;
-              const double a1 = (double)at(j + 1 <= jhi ? j + 1 : jhi);
-              x = (fr == 0.0) ? (float)a0 : (float)__dadd_rn(__dmul_rn(a1 - a0, fr), a0);
-            }
-          } else {
-            x = speed_eval(c, cur[u]);          // span too wide for the buffer (speed rate > ~20)
-          }
-        }
-        v[u] = x;
+        const bool in = cur[u] >= 0 && cur[u] < c.len1;
+        const double pos = speed_pos(c, in ? cur[u] : 0);
+        const bool at_end = pos >= (double)last;
+        // (indices are inside [jlo, jhi] by construction; the clamps keep a mistake in
+        // the hull above a wrong value instead of a stray LDS access)
+        const int j = at_end ? last : (int)pos;
+        const int k0 = min(max(j - jlo, 0), AUXF - 1);
+        const int k1 = min(max((j + 1 <= jhi ? j + 1 : jhi) - jlo, 0), AUXF - 1);
+        const double a0 = (double)aux[k0], a1 = (double)aux[k1];
+        const double fr = pos - (double)j;
+        const float mid = (float)__dadd_rn(__dmul_rn(a1 - a0, fr), a0);
+        const float x = (at_end || fr == 0.0) ? (float)a0 : mid;
+        v[u] = in ? x : 0.f;
       }
       seg_apply<U>(c, c.speed_at + 1, c.n_ops, c.len1, cur, v);
 #pragma unroll
@@ -1063,7 +1101,7 @@ __global__ __launch_bounds__(256) void resolve_partial_kernel(const FrontArgs a,
   const int per = (L + kResolveParts - 1) / kResolveParts;
   const int lo = part * per, hi = (lo + per < L) ? lo + per : L;
   double s1 = 0.0, s2 = 0.0;
-  if (c.speed_at < 0 || c.speed_at >= k0) {
+  if (cc.cops && (c.speed_at < 0 || c.speed_at >= k0)) {
     constexpr int U = 8;
     const int S = seg_shift_sum(cc, 0, k0);
     for (int i0 = lo + (int)threadIdx.x; i0 < hi; i0 += 256 * U) {
@@ -1071,8 +1109,7 @@ __global__ __launch_bounds__(256) void resolve_partial_kernel(const FrontArgs a,
       float v[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) cur[u] = (i0 + 256 * u < hi) ? i0 + 256 * u + S : kDeadIndex;
-#pragma unroll
-      for (int u = 0; u < U; ++u) v[u] = (cur[u] >= 0 && cur[u] < c.len0) ? src.at(cur[u]) : 0.f;
+      src.gather<U>(cur, c.len0, v);
       seg_apply<U>(cc, 0, k0, c.len0, cur, v);
 #pragma unroll
       for (int u = 0; u < U; ++u)
