@@ -691,19 +691,21 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
       }
     } else {
       stagger();
-      constexpr int kBatch = 7;                 // 41 positions per thread in 6 batches of 7
+      // boundary tiles (reflection, end of the utterance): 41 positions per thread in 2 batches,
+      // gathered branch-free (Source::gather) so that a batch is one HBM round trip
+      constexpr int kBatch = 21;
       for (int q0 = tid; q0 < kBlockSamples; q0 += 256 * kBatch) {
         float vals[kBatch];
+        int idx[kBatch];
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
           const int q = q0 + 256 * u;
           int i = p0 + q - kHalf;               // index into the length-n padded utterance
-          if (i < 0) i = -i;                    // torch.stft center=True, pad_mode="reflect"
-          if (i >= n) i = 2 * (n - 1) - i;
-          float v = 0.f;                        // right zero padding (padding_value 0.0)
-          if (q < kBlockSamples && i >= 0 && i < len) v = src.at(i);
-          vals[u] = v;
+          i = (i < 0) ? -i : i;                 // torch.stft center=True, pad_mode="reflect"
+          i = (i >= n) ? 2 * (n - 1) - i : i;
+          idx[u] = (q < kBlockSamples) ? i : -1;
         }
+        src.gather<kBatch>(idx, len, vals);     // 0 outside [0, len): right zero padding (padding_value 0.0)
 #pragma unroll
         for (int u = 0; u < kBatch; ++u) {
           const int q = q0 + 256 * u;
