@@ -1264,9 +1264,18 @@ __global__ __launch_bounds__(256) void resample_kernel(const ResampleArgs a) {
   const long long lo = n0 * a.M / a.L - a.k0;
   const long long hi = n_last * a.M / a.L - a.k0 + a.taps - 1;
   const int span = (int)(hi - lo + 1);                 // <= kRsSpanFloats (checked by the host)
-  for (int i = tid; i < span; i += 256) {
-    const long long k = lo + i;
-    xs[i] = (k >= 0 && k < len_in) ? src.at((int)k) : 0.f;
+  for (int i0 = tid; i0 < span; i0 += 256 * 8) {        // 8 loads in flight per thread, branch-free (Source::gather)
+    int idx[8];
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long k = lo + i0 + 256 * u;
+      idx[u] = (i0 + 256 * u < span && k >= 0 && k < len_in) ? (int)k : -1;
+    }
+    src.gather<8>(idx, len_in, v);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + 256 * u < span) xs[i0 + 256 * u] = v[u];
   }
   int phase[U], xoff[U];
   float acc[U];
@@ -1330,6 +1339,10 @@ __global__ __launch_bounds__(256) void reverb_kernel(const ReverbArgs a) {
     for (long long n = n0 + tid; n < n_end; n += 256) o[n] = n < len ? x[n] : 0.f;
     return;
   }
+  Source xsrc;
+  xsrc.w = x;
+  xsrc.pcm = nullptr;
+  xsrc.ch = 1;
   const long long h0 = a.rir_off[ri];
   const int lr = (int)(a.rir_off[ri + 1] - h0);
   const int c = (lr - 1) / 2;
@@ -1341,9 +1354,18 @@ __global__ __launch_bounds__(256) void reverb_kernel(const ReverbArgs a) {
     // inputs touched by taps [k0, k0 + kc): s = n + c - k, n in [n0, n0 + 2048)
     const long long s_lo = n0 + c - (k0 + kc - 1);
     __syncthreads();
-    for (int i = tid; i < kRvOut + kc - 1; i += 256) {
-      const long long s2 = s_lo + i;
-      xs[i] = (s2 >= 0 && s2 < len) ? x[s2] : 0.f;
+    for (int i0 = tid; i0 < kRvOut + kc - 1; i0 += 256 * 10) {   // the whole span in one batch of 10 loads per thread
+      int idx[10];
+      float v[10];
+#pragma unroll
+      for (int u = 0; u < 10; ++u) {
+        const long long s2 = s_lo + i0 + 256 * u;
+        idx[u] = (i0 + 256 * u < kRvOut + kc - 1 && s2 >= 0 && s2 < len) ? (int)s2 : -1;
+      }
+      xsrc.gather<10>(idx, len, v);
+#pragma unroll
+      for (int u = 0; u < 10; ++u)
+        if (i0 + 256 * u < kRvOut + kc - 1) xs[i0 + 256 * u] = v[u];
     }
     for (int i = tid; i < kc; i += 256) hs[i] = a.rir[h0 + k0 + i];
     __syncthreads();
