@@ -140,6 +140,14 @@ struct Source {
     } else if (ch == 1) {
 #pragma unroll
       for (int u = 0; u < U; ++u) v[u] = (float)pcm[idx[u]] * kScale;
+    } else if (ch == 2 && (reinterpret_cast<uintptr_t>(pcm) & 3u) == 0) {
+      const int* __restrict__ pairs = reinterpret_cast<const int*>(pcm);       // a stereo frame = one aligned dword
+      int raw[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) raw[u] = pairs[idx[u]];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        v[u] = __fdiv_rn((float)((int)(short)(raw[u] & 0xffff) + (raw[u] >> 16)) * kScale, 2.0f);
     } else {
 #pragma unroll
       for (int u = 0; u < U; ++u) v[u] = at(idx[u]);
