@@ -633,9 +633,15 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   const f32x4* __restrict__ gtab = reinterpret_cast<const f32x4*>(a.dft_tab) + tid;
   f32x4* const slots = reinterpret_cast<f32x4*>(lds + kLdsWaveFloats);       // 2 x 512 float4
   f32x4 g0 = gtab[0], g1 = gtab[256], g2 = gtab[512], g3 = gtab[768];
-  f32x4 ga[2], gb[2];                      // staging registers, ping-pong: A(s+2) / A(s+3)
-  ga[0] = gtab[1024];
-  ga[1] = gtab[1280];
+  // three staging sets in rotation: the twiddles of step s+4 are requested in step s and
+  // parked in LDS in step s+2 (two whole steps for the L2 round trip under load)
+  f32x4 G[3][2];
+  G[1][0] = gtab[1024];                    // A(2), written out in step 0
+  G[1][1] = gtab[1280];
+  G[2][0] = gtab[1536];                    // A(3), written out in step 1
+  G[2][1] = gtab[1792];
+  G[0][0] = G[1][0];
+  G[0][1] = G[1][1];
 
   // ---- stage the padded-signal span [160 t0, 160 t0 + 10480) into LDS
   {
@@ -750,8 +756,8 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   // workgroup instead of once per wave.  Everything a step consumes was requested
   // a whole step earlier, and the requests are dealt out between the MFMAs of the
   // step in four small batches so that the matrix pipe never waits on their issue:
-  //   step s:  MFMA 1,2    | global->reg A(s+3) (2 x 16 B/thread)
-  //            MFMA 3,4    | reg->LDS A(s+2) into slot s&1 (fetched during step s-1; the slot was
+  //   step s:  MFMA 1,2    | global->reg A(s+4) (2 x 16 B/thread), three register sets in rotation
+  //            MFMA 3,4    | reg->LDS A(s+2) into slot s&1 (fetched during step s-2; the slot was
   //                        |   read out in step s-1)
   //            MFMA 5..12  | LDS->reg the 8 fragment pieces of A(s+1)
   //            MFMA 13..16 | LDS->reg the 4 samples of step s+1
@@ -803,15 +809,15 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
       acc[g][bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rc[g].at(bt), (g & 1) ? o[g >> 1] : e[g >> 1], acc[g][bt],
                                                         0, 0, 0);
     };
-    f32x4(&Gw)[2] = (s & 1) ? gb : ga;      // holds A(s+2), requested during step s-1
-    f32x4(&Gr)[2] = (s & 1) ? ga : gb;      // receives A(s+3)
+    f32x4(&Gw)[2] = G[(s + 1) % 3];         // holds A(s+2), requested during step s-2
+    f32x4(&Gr)[2] = G[s % 3];               // receives A(s+4)
     // the 16 requests of a step, one behind each of the first 16 MFMAs (a clump of
     // them between two MFMAs idles the matrix pipe for the clump's issue time)
     auto request = [&](int i) {
       if (i < 2) {                                          // global -> registers, A(s+3)
         // uniform base + 32-bit thread offset: a scalar-base load, no 64-bit VALU address math
-        if (s + 3 < kSteps)
-          Gr[i] = reinterpret_cast<const f32x4*>(a.dft_tab)[(s + 3) * 512 + 256 * i + (unsigned)tid];
+        if (s + 4 < kSteps)
+          Gr[i] = reinterpret_cast<const f32x4*>(a.dft_tab)[(s + 4) * 512 + 256 * i + (unsigned)tid];
       } else if (i < 4) {                                   // registers -> LDS, A(s+2)
         if (stage) slots[(s & 1) * 512 + 256 * (i - 2) + tid] = Gw[i - 2];
       } else if (i < 12) {                                  // LDS -> registers, fragments of A(s+1)
