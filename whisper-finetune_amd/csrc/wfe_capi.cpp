@@ -20,7 +20,7 @@ struct wfe_context {
   wfe_config cfg;
   float* d_dft = nullptr;
   float* d_mel = nullptr;
-  unsigned* d_clip_max = nullptr;       // kMaxBatchPerLaunch words
+  unsigned* d_tickets = nullptr;        // kCuTickets per-CU arrival counters (stagger heuristic of kernel 1)
   wfe::Resolved* d_resolved = nullptr;  // grows on demand
   size_t resolved_cap = 0;
   double* d_noise_meansq = nullptr;     // grows on demand
@@ -42,8 +42,8 @@ struct wfe_context {
     int L = 0, M = 0, taps = 0, k0 = 0;
   };
   std::map<std::pair<int, int>, RsTable> rs_tables;   // (in_rate, out_rate) -> filter on the device
-  float* d_block_min = nullptr;             // per-wave minima of kernel 1, grows on demand
-  size_t block_min_cap = 0;
+  float* d_tile_stats = nullptr;            // per-tile minima / maxima of kernel 1, grows on demand
+  size_t tile_stats_cap = 0;
   unsigned long long* d_stamps = nullptr;   // diagnostic builds only (wfe_debug_stamps)
   std::string err;
 };
@@ -115,9 +115,8 @@ void fill_args(wfe_context* h, wfe::FrontArgs& a, const void* wav_or_pcm, int ch
   a.dft_tab = h->d_dft;
   a.mel_tab = h->d_mel;
   std::memcpy(a.mel_mask, h->mel_mask, sizeof a.mel_mask);
-  a.clip_max = h->d_clip_max;
-  a.cu_tickets = h->d_clip_max + kMaxBatchPerLaunch;
-  a.block_min = h->d_block_min;
+  a.cu_tickets = h->d_tickets;
+  a.tile_stats = h->d_tile_stats;
   a.stamps = h->d_stamps;
 }
 
@@ -182,13 +181,13 @@ int run_frontend(wfe_context* h, const void* wav, int channels, const int64_t* o
   const int T = n_samples / wfe::kHop;
   if (mode == 0) {
     const size_t per_slice = (size_t)(batch < kMaxBatchPerLaunch ? batch : kMaxBatchPerLaunch) *
-                             ((T + wfe::kBlockFrames - 1) / wfe::kBlockFrames) * 8;
-    if (per_slice > h->block_min_cap) {
-      if (h->d_block_min) HIP_TRY(h, hipFree(h->d_block_min));
-      h->d_block_min = nullptr;
-      h->block_min_cap = 0;
-      HIP_TRY(h, hipMalloc(&h->d_block_min, per_slice * 2 * sizeof(float)));
-      h->block_min_cap = per_slice * 2;
+                             ((T + wfe::kBlockFrames - 1) / wfe::kBlockFrames) * wfe::kTileStats;
+    if (per_slice > h->tile_stats_cap) {
+      if (h->d_tile_stats) HIP_TRY(h, hipFree(h->d_tile_stats));
+      h->d_tile_stats = nullptr;
+      h->tile_stats_cap = 0;
+      HIP_TRY(h, hipMalloc(&h->d_tile_stats, per_slice * 2 * sizeof(float)));
+      h->tile_stats_cap = per_slice * 2;
     }
   }
   const long long per_clip = (mode == 1) ? (long long)wfe::kNfreq * T : (long long)h->cfg.n_mel * T;
@@ -210,9 +209,9 @@ int run_frontend(wfe_context* h, const void* wav, int channels, const int64_t* o
       a.resolved = h->d_resolved;
       HIP_TRY(h, wfe::launch_resolve(a, s.count, h->d_partials, stream));
     }
-    // clip maxima of this slice and the per-CU arrival tickets (contiguous): one memset
+    // the per-CU arrival tickets of kernel 1's stagger heuristic
     if (mode == 0)
-      HIP_TRY(h, hipMemsetAsync(h->d_clip_max, 0, sizeof(unsigned) * (kMaxBatchPerLaunch + kCuTickets), stream));
+      HIP_TRY(h, hipMemsetAsync(h->d_tickets, 0, sizeof(unsigned) * kCuTickets, stream));
     hipEvent_t* ev = nullptr;
     if (h->timing) {
       if (h->ev_used + 3 > h->ev_pool.size()) {
@@ -229,7 +228,7 @@ int run_frontend(wfe_context* h, const void* wav, int channels, const int64_t* o
     HIP_TRY(h, wfe::launch_frontend(a, s.count, mode, aug, h->bank, stream));
     if (ev) HIP_TRY(h, hipEventRecord(ev[1], stream));
     if (mode == 0)
-      HIP_TRY(h, wfe::launch_clamp(a.out, h->d_clip_max, h->d_block_min, s.count, h->cfg.n_mel, T, stream));
+      HIP_TRY(h, wfe::launch_clamp(a.out, h->d_tile_stats, s.count, h->cfg.n_mel, T, stream));
     if (ev) HIP_TRY(h, hipEventRecord(ev[2], stream));
   }
   return WFE_OK;
@@ -279,7 +278,7 @@ int wfe_create(const wfe_config* cfg, wfe_handle* out) {
   hipError_t e = guard.ok ? hipSuccess : hipErrorInvalidDevice;
   if (e == hipSuccess) e = hipMalloc(&h->d_dft, dft.size() * sizeof(float));
   if (e == hipSuccess) e = hipMalloc(&h->d_mel, mel.size() * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc(&h->d_clip_max, sizeof(unsigned) * (kMaxBatchPerLaunch + kCuTickets));
+  if (e == hipSuccess) e = hipMalloc(&h->d_tickets, sizeof(unsigned) * kCuTickets);
   if (e == hipSuccess) e = hipMemcpy(h->d_dft, dft.data(), dft.size() * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(h->d_mel, mel.data(), mel.size() * sizeof(float), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -296,10 +295,10 @@ int wfe_destroy(wfe_handle h) {
   DeviceGuard guard(h->cfg.device);
   if (h->d_dft) (void)hipFree(h->d_dft);
   if (h->d_mel) (void)hipFree(h->d_mel);
-  if (h->d_clip_max) (void)hipFree(h->d_clip_max);
+  if (h->d_tickets) (void)hipFree(h->d_tickets);
   if (h->d_resolved) (void)hipFree(h->d_resolved);
   if (h->d_noise_meansq) (void)hipFree(h->d_noise_meansq);
-  if (h->d_block_min) (void)hipFree(h->d_block_min);
+  if (h->d_tile_stats) (void)hipFree(h->d_tile_stats);
   for (auto& kv : h->rs_tables)
     if (kv.second.d) (void)hipFree(kv.second.d);
   if (h->d_partials) (void)hipFree(h->d_partials);

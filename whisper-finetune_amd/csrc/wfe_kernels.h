@@ -15,6 +15,8 @@ struct Resolved {
   float b;
 };
 
+constexpr int kTileStats = 12;   // floats kernel 1 leaves per 64-frame tile for kernel 2
+
 struct FrontArgs {
   // input
   const float* wav;              // float32 samples, or
@@ -32,9 +34,8 @@ struct FrontArgs {
   unsigned mel_mask[14];
   // output
   float* out;                    // (B, n_mel, T) log10 mel power, or (B, 201, T) power
-  unsigned* clip_max;            // (B) order-preserving encoding of max log10
-  float* block_min;              // (B x 64-frame tiles x 4 frame groups x 2) minimum log10 mel seen by each wave
-  unsigned* cu_tickets;          // (4096) arrival counters per CU, zeroed with clip_max (stagger heuristic)
+  float* tile_stats;             // (B x 64-frame tiles x kTileStats): log10 mel minima [frame group 4][2], maxima [wave 4]
+  unsigned* cu_tickets;          // (4096) arrival counters per CU, zeroed before the launch (stagger heuristic)
   // augmentation (AUG kernels only)
   const wfe_aug_op* ops;
   const int* op_begin;
@@ -48,8 +49,7 @@ struct FrontArgs {
 // mode 0: log10 mel + clip max.  mode 1: power spectrum.
 hipError_t launch_frontend(const FrontArgs& a, int batch, int mode, bool augmented, int bank, hipStream_t stream);
 // max(stored, g(max-8)) over the tiles whose minimum is below max-8 (kernel 1 stored g(v) = (v+4)/4)
-hipError_t launch_clamp(float* out, const unsigned* clip_max, const float* block_min, int batch, int n_mel,
-                        int n_frames, hipStream_t stream);
+hipError_t launch_clamp(float* out, const float* tile_stats, int batch, int n_mel, int n_frames, hipStream_t stream);
 // partial sums of squares of the noise clips: meansq has n_noise x kNoiseParts doubles
 constexpr int kNoiseParts = 16;
 hipError_t launch_noise_meansq(const float* noise, const long long* noise_off, int n_noise, double* meansq,

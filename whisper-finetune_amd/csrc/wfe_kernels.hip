@@ -17,8 +17,8 @@
 // registers one step ahead), one barrier per k-step.  The butterflies
 // Ce+-Co / Se+-So and |.|^2 run on the accumulators, whose C/D layout (frame on
 // the lane, bins in registers) is exactly the B layout the mel MFMA wants, so the
-// power spectrum never leaves registers.  Epilogue: log10, per-wave max ->
-// one atomicMax per wave on the utterance's max word; the block's (n_mel x 64)
+// power spectrum never leaves registers.  Epilogue: log10, per-wave max / min ->
+// plain stores into the tile's statistics; the block's (n_mel x 64)
 // output tile is transposed through LDS and leaves as 256-byte row segments.
 //
 // Kernel 2 (clamp_kernel): kernel 1 stores (x + 4) / 4 and each workgroup's minimum;
@@ -70,14 +70,6 @@ __device__ __forceinline__ Frag7 load_frag7(const f32x4* p) {
 }
 
 // ------------------------------------------------------------------ utilities
-__device__ __forceinline__ unsigned enc_max(float v) {
-  const unsigned u = __float_as_uint(v);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float dec_max(unsigned k) {
-  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
-}
-
 // max / min over the 64 lanes without LDS traffic (ds_bpermute queues behind the
 // partner workgroup's k-loop reads): four DPP row rotations leave every lane with
 // its row's value, four v_readlane combine the rows.  Result uniform.
@@ -585,8 +577,8 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
         // Nothing is written here: the tile is the constant g(-10) = -1.5 before the
         // clamp, so kernel 2 (which knows the utterance maximum) writes its final value
         // once.  -inf marks the tile as silent; real minima are >= -10.
-        if (tid == 0) atomicMax(a.clip_max + b, enc_max(-10.0f));
-        if (tid < 8) a.block_min[((long long)b * nblk + blockIdx.x) * 8 + tid] = -INFINITY;
+        if (tid < kTileStats)
+          a.tile_stats[((long long)b * nblk + blockIdx.x) * kTileStats + tid] = tid < 8 ? -INFINITY : -10.0f;
       }
       return;
     }
@@ -963,9 +955,10 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   wmax = wave_reduce<true>(wmax);
   wmin = wave_reduce<false>(wmin);
   if (lane == 0) {
-    if (wmax > -INFINITY) atomicMax(a.clip_max + b, enc_max(wmax));
-    a.block_min[((long long)b * nblk + blockIdx.x) * 8 + 2 * wave] = wmin;      // both halves of the
-    a.block_min[((long long)b * nblk + blockIdx.x) * 8 + 2 * wave + 1] = wmin;  // frame group's pair
+    float* st = a.tile_stats + ((long long)b * nblk + blockIdx.x) * kTileStats;
+    st[2 * wave] = wmin;                 // both entries of the frame group's pair
+    st[2 * wave + 1] = wmin;
+    st[8 + wave] = wmax;                 // plain stores: kernel 2 reduces the maxima (no atomics, no zeroing)
   }
   __syncthreads();
   float* __restrict__ lo = a.out + (long long)b * a.n_mel * T + t0;
@@ -997,11 +990,21 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
 // workgroups; g is monotone, so the result is max(stored, g(max - 8)) bit for bit, and
 // a workgroup's (n_mel x 64) tile needs touching only when its minimum is below
 // max - 8.  One workgroup here per workgroup of kernel 1: most exit after 5 loads.
-__global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ out, const unsigned* __restrict__ clip_max,
-                                                    const float* __restrict__ block_min, int n_mel, int T) {
+__global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ out, const float* __restrict__ tile_stats,
+                                                    int n_mel, int T) {
+  __shared__ float sh[4];
   const int b = blockIdx.y;
-  const float floor_v = dec_max(clip_max[b]) - 8.0f;
-  const float* bm = block_min + ((long long)b * gridDim.x + blockIdx.x) * 8;   // [frame group 4][wave of the pair 2]
+  const int nblk = gridDim.x;
+  // log_spec.max() of the utterance (HF:161): the maximum of the per-wave maxima kernel 1 left
+  float gmax = -INFINITY;
+  for (int i = threadIdx.x; i < nblk * 4; i += 256)
+    gmax = fmaxf(gmax, tile_stats[((long long)b * nblk + (i >> 2)) * kTileStats + 8 + (i & 3)]);
+  gmax = wave_reduce<true>(gmax);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = gmax;
+  __syncthreads();
+  gmax = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+  const float floor_v = gmax - 8.0f;
+  const float* bm = tile_stats + ((long long)b * nblk + blockIdx.x) * kTileStats;   // [frame group 4][wave of the pair 2]
   // decided per half tile (32 frames): two frame groups, each with the minima of its (up to two) waves
   const int tid = threadIdx.x;
   const float floor_g = (floor_v + 4.0f) * 0.25f;
@@ -1445,10 +1448,9 @@ hipError_t launch_frontend(const FrontArgs& a, int batch, int mode, bool aug, in
   return aug ? launch_k1<8, false, true, 0>(a, batch, stream) : launch_k1<8, false, false, 0>(a, batch, stream);
 }
 
-hipError_t launch_clamp(float* out, const unsigned* clip_max, const float* block_min, int batch, int n_mel,
-                        int n_frames, hipStream_t stream) {
+hipError_t launch_clamp(float* out, const float* tile_stats, int batch, int n_mel, int n_frames, hipStream_t stream) {
   const dim3 grid((n_frames + kBlockFrames - 1) / kBlockFrames, batch);
-  hipLaunchKernelGGL(clamp_kernel, grid, dim3(256), 0, stream, out, clip_max, block_min, n_mel, n_frames);
+  hipLaunchKernelGGL(clamp_kernel, grid, dim3(256), 0, stream, out, tile_stats, n_mel, n_frames);
   return hipGetLastError();
 }
 
