@@ -23,7 +23,7 @@ lib = _lib.lib()
 lib.wfe_debug_stamps.restype = C.c_int
 lib.wfe_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
 blocks = B * 47
-stamps = torch.zeros((blocks * 4, 8), dtype=torch.int64, device="cuda")
+stamps = torch.zeros((blocks * 4, 16), dtype=torch.int64, device="cuda")
 wav = 0.1 * torch.randn((B, 480000), device="cuda")
 lens = torch.full((B,), 480000, dtype=torch.int32, device="cuda")
 run = lambda: fe.logmel(wav, lens)                                   # noqa: E731
@@ -58,6 +58,15 @@ for i, nme in enumerate(names):
 tot = s[:, 5] - s[:, 0]
 print(f"{'  k-loop barrier waits':22s} median {np.median(s[:, 7]):9.0f}  (sum over 24 barriers incl. 2 stamps each)")
 print(f"{'total':22s} median {np.median(tot):9.0f}  p10 {np.percentile(tot, 10):9.0f}  p90 {np.percentile(tot, 90):9.0f}")
+
+if os.environ.get("WFE_PHASE_AUG") == "1":           # slots 8..11 carry the staging passes of SPEED chains
+    tA, tW, tB, npass = s[:, 8], s[:, 9], s[:, 10], s[:, 11]
+    sp = npass > 0
+    print("speed tiles: %d of %d waves; passes median %.0f" % (sp.sum(), len(s), np.median(npass[sp])))
+    for nme, v in (("pass A (seg0 -> LDS)", tA), ("barrier waits", tW), ("pass B (interp+seg1)", tB)):
+        print(f"  {nme:22s} median {np.median(v[sp]):9.0f}  p10 {np.percentile(v[sp], 10):9.0f}  p90 {np.percentile(v[sp], 90):9.0f}")
+    print("  staging total: speed tiles median %.0f, other tiles median %.0f" % (np.median(d[sp, 0]), np.median(d[~sp, 0])))
+    sys.exit(0)
 
 # co-residency: group waves by (xcc, se/sh/cu, simd) and measure how much of each wave's
 # k-loop overlaps another wave's k-loop on the same SIMD

@@ -43,7 +43,7 @@ struct FrontArgs {
   const long long* noise_off;
   const double* noise_meansq;    // (n_noise x kNoiseParts) partial sums of squares of each noise clip
   Resolved* resolved;            // (total ops) filled by the reduce kernel
-  unsigned long long* stamps;    // diagnostic builds (-DWFE_STAMPS) only: 8 clock stamps per wave
+  unsigned long long* stamps;    // diagnostic builds (-DWFE_STAMPS) only: 16 clock stamps per wave
 };
 
 // mode 0: log10 mel + clip max.  mode 1: power spectrum.

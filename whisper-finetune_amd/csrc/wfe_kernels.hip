@@ -37,12 +37,13 @@ namespace wfe {
 // Diagnostic build only (make stamps): s_memtime at the phase boundaries of kernel
 // 1, written to a buffer nothing else reads.  The shipped library executes none.
 #ifdef WFE_STAMPS
+constexpr int kStampRow = 16;   // 0..5 phase boundaries, 6/7 stagger + k-loop waits, 8..11 staging passes of SPEED chains
 #define WFE_STAMP(i)                                                                   \
   do {                                                                                 \
     if (a.stamps && lane == 0) {                                                       \
       unsigned long long t_;                                                           \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
-      a.stamps[((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + blockIdx.x) * 4 + wave) * 8 + (i)] = t_; \
+      a.stamps[((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + blockIdx.x) * 4 + wave) * kStampRow + (i)] = t_; \
     }                                                                                  \
   } while (0)
 #else
@@ -70,6 +71,25 @@ __device__ __forceinline__ Frag7 load_frag7(const f32x4* p) {
 }
 
 // ------------------------------------------------------------------ utilities
+// ---- single, un-contracted IEEE operations.  hipcc compiles device code with
+// -ffp-contract=fast and HIP's __fmul_rn / __fadd_rn are the plain operators, so
+// a * b + c written with them can still become one fma (it did: 5 % of the noise-mixed
+// samples were one ulp off numpy's three separate float32 passes).  An instruction
+// emitted under contract(off) carries no `contract` flag and is never fused, inlined or not.
+#define WFE_EXACT_OP(NAME, T, EXPR)                 \
+  __device__ __forceinline__ T NAME(T a, T b) {     \
+    _Pragma("clang fp contract(off)")               \
+    return EXPR;                                    \
+  }
+WFE_EXACT_OP(mul_rn, float, a * b)
+WFE_EXACT_OP(add_rn, float, a + b)
+WFE_EXACT_OP(sub_rn, float, a - b)
+WFE_EXACT_OP(div_rn, float, a / b)
+WFE_EXACT_OP(mul_rn, double, a * b)
+WFE_EXACT_OP(add_rn, double, a + b)
+WFE_EXACT_OP(sub_rn, double, a - b)
+#undef WFE_EXACT_OP
+
 // max / min over the 64 lanes without LDS traffic (ds_bpermute queues behind the
 // partner workgroup's k-loop reads): four DPP row rotations leave every lane with
 // its row's value, four v_readlane combine the rows.  Result uniform.
@@ -109,7 +129,7 @@ struct Source {
     if (ch == 1) return (float)pcm[i] * kScale;
     int t = 0;
     for (int cc = 0; cc < ch; ++cc) t += pcm[(long long)i * ch + cc];
-    return __fdiv_rn((float)t * kScale, (float)ch);
+    return div_rn((float)t * kScale, (float)ch);
   }
   // v[u] = sample cur[u], 0 outside [0, L).  Branch-free: every lane loads (index clamped into
   // the utterance) and the value is selected afterwards -- hipcc turns `in ? w[i] : 0` into a
@@ -139,7 +159,7 @@ struct Source {
       for (int u = 0; u < U; ++u) raw[u] = pairs[idx[u]];
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        v[u] = __fdiv_rn((float)((int)(short)(raw[u] & 0xffff) + (raw[u] >> 16)) * kScale, 2.0f);
+        v[u] = div_rn((float)((int)(short)(raw[u] & 0xffff) + (raw[u] >> 16)) * kScale, 2.0f);
     } else {
 #pragma unroll
       for (int u = 0; u < U; ++u) v[u] = at(idx[u]);
@@ -218,7 +238,7 @@ __device__ inline float seg_eval(const Chain& c, int lo, int hi, int L, int idx,
     const wfe_aug_op op = c.ops[k];
     const bool in = cur >= 0 && cur < L;
     if (op.kind == WFE_AUG_VOLUME) {
-      v = __fmul_rn(v, op.f0);                                   // sample *= 10**(gain/20)
+      v = mul_rn(v, op.f0);                                   // sample *= 10**(gain/20)
     } else if (op.kind == WFE_AUG_SHIFT) {
       if (!in) v = 0.f;                                          // zero-filled region
       cur -= op.i0;
@@ -229,10 +249,10 @@ __device__ inline float seg_eval(const Chain& c, int lo, int hi, int L, int idx,
         const int ln = (int)(c.noise_off[op.i0 + 1] - o0);
         const int j = (ln < L) ? (cur % ln) : (cur + op.i1);     // np.pad 'wrap' | slice at start
         // three separate float32 passes in the reference: no contraction
-        v = __fadd_rn(__fmul_rn(v, r.a), __fmul_rn(c.noise[o0 + j], r.b));
+        v = add_rn(mul_rn(v, r.a), mul_rn(c.noise[o0 + j], r.b));
       }
     } else if (op.kind == WFE_AUG_AFFINE) {
-      if (in) v = __fdiv_rn(__fsub_rn(v, c.res[k].a), c.res[k].b);
+      if (in) v = div_rn(sub_rn(v, c.res[k].a), c.res[k].b);
     }
   }
   return v;
@@ -243,7 +263,7 @@ __device__ inline float speed_eval(const Chain& c, int i) {
   auto raw = [&](int j) { return c.src.at(j); };
   auto s0 = [&](int j) { return seg_eval(c, 0, c.speed_at, c.len0, j, raw); };
   double pos = 0.0;
-  if (c.len1 > 1) pos = (i == c.len1 - 1) ? (double)c.len0 : __dmul_rn((double)i, c.step);
+  if (c.len1 > 1) pos = (i == c.len1 - 1) ? (double)c.len0 : mul_rn((double)i, c.step);
   const int last = c.len0 - 1;
   if (pos >= (double)last) return s0(last);
   const int j = (int)pos;
@@ -251,7 +271,7 @@ __device__ inline float speed_eval(const Chain& c, int i) {
   const double fr = pos - (double)j;
   if (fr == 0.0) return (float)a0;
   const double a1 = (double)s0(j + 1);
-  return (float)__dadd_rn(__dmul_rn(a1 - a0, fr), a0);
+  return (float)add_rn(mul_rn(sub_rn(a1, a0), fr), a0);
 }
 
 // value of the signal after the first n_ops_used ops at index i
@@ -327,7 +347,7 @@ __device__ __forceinline__ void seg_apply(const Chain& c, int lo, int hi, int L,
     const COp op = get_cop(c, k);
     if (op.kind == WFE_AUG_VOLUME) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) v[u] = __fmul_rn(v[u], op.f0);
+      for (int u = 0; u < U; ++u) v[u] = mul_rn(v[u], op.f0);
     } else if (op.kind == WFE_AUG_SHIFT) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -352,11 +372,11 @@ __device__ __forceinline__ void seg_apply(const Chain& c, int lo, int hi, int L,
       }
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (cur[u] >= 0 && cur[u] < L && ln > 0) v[u] = __fadd_rn(__fmul_rn(v[u], op.ra), __fmul_rn(nz[u], op.rb));
+        if (cur[u] >= 0 && cur[u] < L && ln > 0) v[u] = add_rn(mul_rn(v[u], op.ra), mul_rn(nz[u], op.rb));
     } else if (op.kind == WFE_AUG_AFFINE) {
 #pragma unroll
       for (int u = 0; u < U; ++u)
-        if (cur[u] >= 0 && cur[u] < L) v[u] = __fdiv_rn(__fsub_rn(v[u], op.ra), op.rb);
+        if (cur[u] >= 0 && cur[u] < L) v[u] = div_rn(sub_rn(v[u], op.ra), op.rb);
     }
   }
 }
@@ -372,14 +392,28 @@ __device__ __forceinline__ int padded_index(int q, int p0, int n, int len) {
 
 __device__ __forceinline__ double speed_pos(const Chain& c, int i) {
   if (c.len1 <= 1) return 0.0;
-  return (i == c.len1 - 1) ? (double)c.len0 : __dmul_rn((double)i, c.step);
+  return (i == c.len1 - 1) ? (double)c.len0 : mul_rn((double)i, c.step);
 }
 
 // Stages the augmented padded signal of one workgroup into the LDS image.
 // aux: AUXF floats of LDS free during staging (the seg0 buffer of SPEED chains).
 template <int AUXF>
 __device__ inline void stage_augmented(const Chain& c, float* __restrict__ lds, float* __restrict__ aux, int p0, int n,
-                                       int len, int tid) {
+                                       int len, int tid, unsigned long long* st = nullptr) {
+#ifdef WFE_STAMPS
+  unsigned long long tA = 0, tW = 0, tB = 0, np_ = 0, t_prev = 0;
+  auto tick = [&](unsigned long long& acc) {
+    unsigned long long t_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+    acc += t_ - t_prev;
+    t_prev = t_;
+  };
+  { unsigned long long z = 0; tick(z); }
+  if (st) st[8] = st[9] = st[10] = st[11] = 0;
+#define WFE_TICK(acc) tick(acc)
+#else
+#define WFE_TICK(acc) do {} while (0)
+#endif
   if (!c.cops) {                                // more than kMaxCops ops: per-position evaluation from global memory
     for (int q = tid; q < kBlockSamples; q += 256) {
       const int i = padded_index(q, p0, n, len);
@@ -414,113 +448,62 @@ __device__ inline void stage_augmented(const Chain& c, float* __restrict__ lds, 
     return;
   }
 
-  constexpr int U = 11;                         // <= 22 positions per thread and pass: 2 batches (see above)
+  // SPEED chain: np.interp needs seg0 at the two source indices j, j + 1 around every output
+  // position.  Both are evaluated per output position, in the same register batch (2 U
+  // gathers per NOISE op, all in flight together): seg0 is computed twice per sample, but
+  // there is no pass through LDS, no barrier and no limit on the speed rate, and a batch is
+  // one round trip.  (A two-pass version -- seg0 per SOURCE index into LDS, then
+  // interpolation -- measured 39k + 37k cycles per tile in kernel 1: 5 + 4 round trips.)
+  constexpr int U = 11;
   const int S0 = seg_shift_sum(c, 0, c.speed_at);
   const int S1 = seg_shift_sum(c, c.speed_at + 1, c.n_ops);
   const int last = c.len0 - 1;
-  // positions per pass: their source span (C - 1) * step + 3 must fit the buffer
-  int C = kBlockSamples;
-  if (c.step > 1.0) {
-    const double fit = (double)(AUXF - 3) / c.step;
-    if (fit < (double)C) C = (int)fit;
-  } else if (C > AUXF - 3) {
-    C = AUXF - 3;
+  for (int q0 = tid; q0 < kBlockSamples; q0 += 256 * U) {
+    int cur[U], cur0[2 * U];
+    float v[U], v0[2 * U];
+    double fr[U];
+    bool ok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = padded_index(q0 + 256 * u, p0, n, len);
+      ok[u] = i >= 0;
+      cur[u] = ok[u] ? i + S1 : kDeadIndex;
+      const bool in = cur[u] >= 0 && cur[u] < c.len1;
+      const double pos = speed_pos(c, in ? cur[u] : 0);
+      const bool at_end = pos >= (double)last;           // np.interp right of xp[-1]: fp[-1]
+      const int j = at_end ? last : (int)pos;
+      fr[u] = at_end ? 0.0 : pos - (double)j;
+      cur0[2 * u] = in ? j + S0 : kDeadIndex;
+      cur0[2 * u + 1] = in ? (j < last ? j + 1 : last) + S0 : kDeadIndex;
+    }
+    c.src.gather<2 * U>(cur0, c.len0, v0);
+    seg_apply<2 * U>(c, 0, c.speed_at, c.len0, cur0, v0);
+    WFE_TICK(tA);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const double a0 = (double)v0[2 * u], a1 = (double)v0[2 * u + 1];
+      const float mid = (float)add_rn(mul_rn(sub_rn(a1, a0), fr[u]), a0);
+      v[u] = (fr[u] == 0.0) ? v0[2 * u] : mid;           // (out-of-range positions: both gathers are 0)
+    }
+    seg_apply<U>(c, c.speed_at + 1, c.n_ops, c.len1, cur, v);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = q0 + 256 * u;
+      if (q < kBlockSamples) lds[pad_q(q)] = ok[u] ? v[u] : 0.f;
+    }
+    WFE_TICK(tB);
+#ifdef WFE_STAMPS
+    ++np_;
+#endif
   }
-  C = C / 256 * 256;
-  for (int qa = 0; qa < kBlockSamples; qa += (C > 0 ? C : kBlockSamples)) {
-    const int qb = (C > 0 && qa + C < kBlockSamples) ? qa + C : kBlockSamples;
-    // hull of the utterance indices the positions [qa, qb) map to (reflections fold, never stretch)
-    int lo_i = p0 + qa - kHalf, hi_i = p0 + qb - 1 - kHalf;
-    if (hi_i < 0) {
-      const int t = -hi_i;
-      hi_i = -lo_i;
-      lo_i = t;
-    } else if (lo_i < 0) {
-      hi_i = (-lo_i > hi_i) ? -lo_i : hi_i;
-      lo_i = 0;
-    }
-    if (lo_i >= n) {
-      const int t = 2 * (n - 1) - hi_i;
-      hi_i = 2 * (n - 1) - lo_i;
-      lo_i = t;
-    } else if (hi_i >= n) {
-      const int t = 2 * (n - 1) - hi_i;
-      lo_i = t < lo_i ? t : lo_i;
-      hi_i = n - 1;
-    }
-    if (lo_i < 0) lo_i = 0;
-    if (hi_i > len - 1) hi_i = len - 1;
-    int cmin = lo_i + S1, cmax = hi_i + S1;            // indices into the sped-up signal
-    if (cmin < 0) cmin = 0;
-    if (cmax > c.len1 - 1) cmax = c.len1 - 1;
-    const bool any = lo_i <= hi_i && cmin <= cmax && last >= 0;
-    int jlo = 0, jhi = -1;
-    if (any) {
-      const double plo = speed_pos(c, cmin), phi = speed_pos(c, cmax);
-      jlo = plo >= (double)last ? last : (int)plo;
-      jhi = phi >= (double)last ? last : (int)phi + 1;
-      if (jhi > last) jhi = last;
-    }
-    const bool buffered = C > 0 && jhi - jlo + 1 <= AUXF;
-    if (buffered) {
-      // pass A: seg0 at every source index of the span, once
-      for (int j0 = jlo + tid; j0 <= jhi; j0 += 256 * U) {
-        int cur[U];
-        float v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) cur[u] = (j0 + 256 * u <= jhi) ? j0 + 256 * u + S0 : kDeadIndex;
-        c.src.gather<U>(cur, c.len0, v);
-        seg_apply<U>(c, 0, c.speed_at, c.len0, cur, v);
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-          if (j0 + 256 * u <= jhi) aux[j0 + 256 * u - jlo] = v[u];
-      }
-    }
-    __syncthreads();
-    if (!buffered) {
-      // span too wide for the buffer (speed rate > ~20): per-position evaluation of the whole chain
-      for (int q = qa + tid; q < qb; q += 256) {
-        const int i = padded_index(q, p0, n, len);
-        lds[pad_q(q)] = i >= 0 ? chain_eval(c, c.n_ops, i) : 0.f;
-      }
-      __syncthreads();
-      continue;
-    }
-    // pass B: np.interp in float64 between two buffered seg0 values, then seg1.  Branch-free
-    // per element (selects, clamped LDS indices): the U elements stay in one basic block.
-    for (int q0 = qa + tid; q0 < qb; q0 += 256 * U) {
-      int cur[U];
-      float v[U];
-      bool ok[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int q = q0 + 256 * u;
-        const int i = (q < qb) ? padded_index(q, p0, n, len) : -1;
-        ok[u] = i >= 0;
-        cur[u] = ok[u] ? i + S1 : kDeadIndex;
-        const bool in = cur[u] >= 0 && cur[u] < c.len1;
-        const double pos = speed_pos(c, in ? cur[u] : 0);
-        const bool at_end = pos >= (double)last;
-        // (indices are inside [jlo, jhi] by construction; the clamps keep a mistake in
-        // the hull above a wrong value instead of a stray LDS access)
-        const int j = at_end ? last : (int)pos;
-        const int k0 = min(max(j - jlo, 0), AUXF - 1);
-        const int k1 = min(max((j + 1 <= jhi ? j + 1 : jhi) - jlo, 0), AUXF - 1);
-        const double a0 = (double)aux[k0], a1 = (double)aux[k1];
-        const double fr = pos - (double)j;
-        const float mid = (float)__dadd_rn(__dmul_rn(a1 - a0, fr), a0);
-        const float x = (at_end || fr == 0.0) ? (float)a0 : mid;
-        v[u] = in ? x : 0.f;
-      }
-      seg_apply<U>(c, c.speed_at + 1, c.n_ops, c.len1, cur, v);
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int q = q0 + 256 * u;
-        if (q < qb) lds[pad_q(q)] = ok[u] ? v[u] : 0.f;
-      }
-    }
-    __syncthreads();
+#ifdef WFE_STAMPS
+  if (st) {
+    st[8] = tA;
+    st[9] = tW;
+    st[10] = tB;
+    st[11] = np_;
   }
+#endif
 }
 
 // ------------------------------------------------------------- kernel 1
@@ -608,7 +591,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
     if (a.stamps && lane == 0) {
       const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
       const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
-      unsigned long long* st = a.stamps + ((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + blockIdx.x) * 4 + wave) * 8;
+      unsigned long long* st = a.stamps + ((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + blockIdx.x) * 4 + wave) * kStampRow;
       st[6] = ((unsigned long long)xcc << 32) | hw;
       st[7] = ticket;
     }
@@ -624,16 +607,20 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   // waveform is staged, then parked in the two LDS slots
   const f32x4* __restrict__ gtab = reinterpret_cast<const f32x4*>(a.dft_tab) + tid;
   f32x4* const slots = reinterpret_cast<f32x4*>(lds + kLdsWaveFloats);       // 2 x 512 float4
-  f32x4 g0 = gtab[0], g1 = gtab[256], g2 = gtab[512], g3 = gtab[768];
+  f32x4 g0, g1, g2, g3;
   // three staging sets in rotation: the twiddles of step s+4 are requested in step s and
   // parked in LDS in step s+2 (two whole steps for the L2 round trip under load)
   f32x4 G[3][2];
-  G[1][0] = gtab[1024];                    // A(2), written out in step 0
-  G[1][1] = gtab[1280];
-  G[2][0] = gtab[1536];                    // A(3), written out in step 1
-  G[2][1] = gtab[1792];
-  G[0][0] = G[1][0];
-  G[0][1] = G[1][1];
+  auto request_twiddles = [&]() {
+    g0 = gtab[0], g1 = gtab[256], g2 = gtab[512], g3 = gtab[768];
+    G[1][0] = gtab[1024];                  // A(2), written out in step 0
+    G[1][1] = gtab[1280];
+    G[2][0] = gtab[1536];                  // A(3), written out in step 1
+    G[2][1] = gtab[1792];
+    G[0][0] = G[1][0];
+    G[0][1] = G[1][1];
+  };
+  if (!AUG) request_twiddles();            // (AUG: after the staging, which wants the 32 registers itself)
 
   // ---- stage the padded-signal span [160 t0, 160 t0 + 10480) into LDS
   {
@@ -643,7 +630,12 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
                             ((reinterpret_cast<uintptr_t>(src.pcm + i_first) & 15u) == 0);
     if (AUG) {
       stagger();
+#ifdef WFE_STAMPS
+      stage_augmented<kAuxFloats>(c, lds, lds + kLdsWaveFloats, p0, n, len, tid,
+                                  (a.stamps && lane == 0) ? a.stamps + ((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + blockIdx.x) * 4 + wave) * kStampRow : nullptr);
+#else
       stage_augmented<kAuxFloats>(c, lds, lds + kLdsWaveFloats, p0, n, len, tid);
+#endif
     } else if (interior16) {
       // 16-bit PCM: 8 samples per 16-byte load, converted on the way into LDS
       using i32x4 = __attribute__((ext_vector_type(4))) int;
@@ -720,6 +712,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
       }
     }
   }
+  if (AUG) request_twiddles();
   slots[tid] = g0;
   slots[256 + tid] = g1;
   slots[512 + tid] = g2;
@@ -847,7 +840,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   WFE_STAMP(3);
 #ifdef WFE_STAMPS
   if (a.stamps && lane == 0)
-    a.stamps[((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + blockIdx.x) * 4 + wave) * 8 + 7] = barrier_cycles;
+    a.stamps[((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + blockIdx.x) * 4 + wave) * kStampRow + 7] = barrier_cycles;
 #endif
   // Mel weight fragments of every live (bin tile, mel tile) block: all requested
   // here, ahead of the butterflies, so that the mel phase pays one L2 round trip
@@ -1073,7 +1066,7 @@ __global__ __launch_bounds__(256) void noise_meansq_kernel(const float* __restri
   double s = 0.0;
   for (long long i = lo + threadIdx.x; i < hi; i += 256) {
     const float x = noise[o0 + i];
-    s += (double)__fmul_rn(x, x);                    // float32 squares, as sample ** 2
+    s += (double)mul_rn(x, x);                    // float32 squares, as sample ** 2
   }
   s = block_sum<256>(s, sh);
   if (threadIdx.x == 0) partial[(long long)j * kNoiseParts + part] = s;
@@ -1086,7 +1079,7 @@ __device__ inline double noise_meansq(const FrontArgs& a, int j) {
 }
 
 // rms_db (utils/reader.py:350-353) under NumPy-2 float32 scalar semantics
-__device__ inline float rms_db_f32(double meansq) { return __fmul_rn(10.0f, log10f((float)meansq)); }
+__device__ inline float rms_db_f32(double meansq) { return mul_rn(10.0f, log10f((float)meansq)); }
 
 // Statistics of the signal ENTERING the first NOISE / AFFINE op of every utterance
 // (the only one in the reference's configurations), kResolveParts workgroups per
@@ -1134,14 +1127,14 @@ __global__ __launch_bounds__(256) void resolve_partial_kernel(const FrontArgs a,
       for (int u = 0; u < U; ++u)
         if (i0 + 256 * u < hi) {
           s1 += (double)v[u];
-          s2 += (double)__fmul_rn(v[u], v[u]);         // float32 squares, as sample ** 2
+          s2 += (double)mul_rn(v[u], v[u]);         // float32 squares, as sample ** 2
         }
     }
   } else {
     for (int i = lo + (int)threadIdx.x; i < hi; i += 256) {
       const float x = chain_eval(c, k0, i);
       s1 += (double)x;
-      s2 += (double)__fmul_rn(x, x);
+      s2 += (double)mul_rn(x, x);
     }
   }
   s1 = block_sum<256>(s1, sh);
@@ -1182,7 +1175,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const FrontArgs a, const d
       for (int i = threadIdx.x; i < L; i += 256) {
         const float x = chain_eval(c, k, i);
         s1 += (double)x;
-        s2 += (double)__fmul_rn(x, x);
+        s2 += (double)mul_rn(x, x);
       }
       s1 = block_sum<256>(s1, sh);
       s2 = block_sum<256>(s2, sh);
@@ -1192,19 +1185,19 @@ __global__ __launch_bounds__(256) void resolve_kernel(const FrontArgs a, const d
       Resolved r{0.f, 1.f};
       if (kind == WFE_AUG_NOISE) {
         const double ms = L > 0 ? s2 / (double)L : 0.0;
-        const float gain = fminf(300.0f, __fsub_rn(-20.0f, rms_db_f32(ms)));
-        const float g1 = powf(10.0f, __fdiv_rn(gain, 20.0f));
+        const float gain = fminf(300.0f, sub_rn(-20.0f, rms_db_f32(ms)));
+        const float g1 = powf(10.0f, div_rn(gain, 20.0f));
         const float s_db = rms_db_f32(ms * (double)g1 * (double)g1);
         const float n_db = rms_db_f32(noise_meansq(a, c.ops[k].i0));
-        const float ng = fminf(__fsub_rn(__fsub_rn(s_db, n_db), (float)c.ops[k].i2), 300.0f);
+        const float ng = fminf(sub_rn(sub_rn(s_db, n_db), (float)c.ops[k].i2), 300.0f);
         r.a = g1;
-        r.b = powf(10.0f, __fdiv_rn(ng, 20.0f));
+        r.b = powf(10.0f, div_rn(ng, 20.0f));
       } else if (L > 0) {
         const double mean = s1 / (double)L;
         double var = s2 / (double)L - mean * mean;
         if (var < 0.0) var = 0.0;
         r.a = (float)mean;
-        r.b = sqrtf(__fadd_rn((float)var, 1e-7f));
+        r.b = sqrtf(add_rn((float)var, 1e-7f));
       }
       res[k] = r;
     }
@@ -1420,10 +1413,10 @@ __global__ __launch_bounds__(256) void reverb_scale_kernel(const ReverbArgs a) {
   if (a.rir_index[b] < 0) return;
   int len = a.lengths[b];
   if (len > a.out_stride) len = (int)a.out_stride;
-  const float rate = __fdiv_rn(__uint_as_float(a.peaks[2 * b]), __uint_as_float(a.peaks[2 * b + 1]));
+  const float rate = div_rn(__uint_as_float(a.peaks[2 * b]), __uint_as_float(a.peaks[2 * b + 1]));
   float* __restrict__ o = a.out + (long long)b * a.out_stride;
   for (long long n = (long long)blockIdx.x * 256 + threadIdx.x; n < len; n += (long long)gridDim.x * 256)
-    o[n] = __fmul_rn(o[n], rate);
+    o[n] = mul_rn(o[n], rate);
 }
 
 // ------------------------------------------------------------- launchers
