@@ -60,12 +60,13 @@ print(f"{'  k-loop barrier waits':22s} median {np.median(s[:, 7]):9.0f}  (sum ov
 print(f"{'total':22s} median {np.median(tot):9.0f}  p10 {np.percentile(tot, 10):9.0f}  p90 {np.percentile(tot, 90):9.0f}")
 
 if os.environ.get("WFE_PHASE_AUG") == "1":           # slots 8..11 carry the staging passes of SPEED chains
-    tA, tW, tB, npass = s[:, 8], s[:, 9], s[:, 10], s[:, 11]
-    sp = npass > 0
-    print("speed tiles: %d of %d waves; passes median %.0f" % (sp.sum(), len(s), np.median(npass[sp])))
-    for nme, v in (("pass A (seg0 -> LDS)", tA), ("barrier waits", tW), ("pass B (interp+seg1)", tB)):
-        print(f"  {nme:22s} median {np.median(v[sp]):9.0f}  p10 {np.percentile(v[sp], 10):9.0f}  p90 {np.percentile(v[sp], 90):9.0f}")
-    print("  staging total: speed tiles median %.0f, other tiles median %.0f" % (np.median(d[sp, 0]), np.median(d[~sp, 0])))
+    t0, t1, t2, nb = s[:, 8], s[:, 9], s[:, 10], s[:, 11]
+    for nme, sel in (("3-batch tiles (SPEED)", nb >= 3), ("2-batch tiles", nb == 2)):
+        if not sel.any():
+            continue
+        print(f"{nme}: {sel.sum()} of {len(s)} waves; staging phase median {np.median(d[sel, 0]):.0f}")
+        for lab, v in (("indices + noise addresses", t0), ("gathers (issue + wait)", t1), ("arithmetic + LDS writes", t2)):
+            print(f"  {lab:26s} median {np.median(v[sel]):9.0f}  p10 {np.percentile(v[sel], 10):9.0f}  p90 {np.percentile(v[sel], 90):9.0f}")
     sys.exit(0)
 
 # co-residency: group waves by (xcc, se/sh/cu, simd) and measure how much of each wave's

@@ -135,6 +135,29 @@ struct Source {
   // the utterance) and the value is selected afterwards -- hipcc turns `in ? w[i] : 0` into a
   // branch per element, each load in a basic block of its own with a full wait behind it, which
   // serialises the U round trips.  The format test is outside the unrolled loop for the same reason.
+  // v[u] = sample idx[u]; every index is valid (the caller clamped it).  No selects at all.
+  template <int U>
+  __device__ __forceinline__ void load(const int (&idx)[U], float (&v)[U]) const {
+    constexpr float kScale = 1.0f / 32768.0f;
+    if (!pcm) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = w[idx[u]];
+    } else if (ch == 1) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = (float)pcm[idx[u]] * kScale;
+    } else if (ch == 2 && (reinterpret_cast<uintptr_t>(pcm) & 3u) == 0) {
+      const int* __restrict__ pairs = reinterpret_cast<const int*>(pcm);       // a stereo frame = one aligned dword
+      int raw[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) raw[u] = pairs[idx[u]];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        v[u] = div_rn((float)((int)(short)(raw[u] & 0xffff) + (raw[u] >> 16)) * kScale, 2.0f);
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = at(idx[u]);
+    }
+  }
   template <int U>
   __device__ __forceinline__ void gather(const int (&cur)[U], int L, float (&v)[U]) const {
     constexpr float kScale = 1.0f / 32768.0f;
@@ -340,9 +363,44 @@ __device__ __forceinline__ int seg_shift_sum(const Chain& c, int lo, int hi) {
   return s;
 }
 
-// v[u] = input at cur[u] (0 outside [0, L)); applies ops [lo, hi) in order
+// nz[u] = the sample of NOISE op `op`'s clip that meets segment index cur[u] - back: np.pad(...,
+// 'wrap') of a shorter clip, the slice at op.i1 of a longer one.  Branch-free (clamped index;
+// lanes outside the segment read a valid sample that the caller drops).
 template <int U>
-__device__ __forceinline__ void seg_apply(const Chain& c, int lo, int hi, int L, int (&cur)[U], float (&v)[U]) {
+__device__ __forceinline__ void noise_gather(const Chain& c, const COp& op, int L, const int (&cur)[U], int back,
+                                             float (&nz)[U]) {
+  const int ln = op.ln;
+  // (uniform conditions stay OUTSIDE the unrolled loops: hipcc does not unswitch them, and a
+  // branch per element puts every load into a basic block of its own with a wait behind it)
+  if (ln <= 0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) nz[u] = 0.f;
+    return;
+  }
+  int j[U];
+  if (ln < L) {                                     // cu % ln without the integer divide
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int cu = cur[u] - back;
+      const int qd = (int)((double)cu * op.inv);
+      int r = cu - qd * ln;
+      r = (r < 0) ? r + ln : r;
+      j[u] = (r >= ln) ? r - ln : r;
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u) j[u] = cur[u] - back + op.i1;
+  }
+  const float* __restrict__ clip = c.noise + op.o0;
+#pragma unroll
+  for (int u = 0; u < U; ++u) nz[u] = clip[min(max(j[u], 0), ln - 1)];
+}
+
+// applies ops [lo, hi) in order to v[u], the segment's input at cur[u] (0 outside [0, L)).
+// k_pre >= 0: the gathers of NOISE op k_pre were issued by the caller (nz_pre).
+template <int U>
+__device__ __forceinline__ void seg_apply(const Chain& c, int lo, int hi, int L, int (&cur)[U], float (&v)[U],
+                                          int k_pre, const float (&nz_pre)[U]) {
   for (int k = lo; k < hi; ++k) {
     const COp op = get_cop(c, k);
     if (op.kind == WFE_AUG_VOLUME) {
@@ -355,30 +413,57 @@ __device__ __forceinline__ void seg_apply(const Chain& c, int lo, int hi, int L,
         cur[u] -= op.i0;
       }
     } else if (op.kind == WFE_AUG_NOISE) {
-      const int ln = op.ln;
-      const bool wrap = ln < L;
       float nz[U];
+      if (k == k_pre) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        int j = cur[u] + op.i1;
-        if (wrap) {                                   // cur % ln without the integer divide
-          const int qd = (int)((double)cur[u] * op.inv);
-          j = cur[u] - qd * ln;
-          j = (j < 0) ? j + ln : j;
-          j = (j >= ln) ? j - ln : j;
-        }
-        j = min(max(j, 0), ln > 0 ? ln - 1 : 0);       // branch-free gather (see Source::gather); unused
-        nz[u] = ln > 0 ? c.noise[op.o0 + j] : 0.f;     // lanes read a valid sample and drop it below
+        for (int u = 0; u < U; ++u) nz[u] = nz_pre[u];
+      } else {
+        noise_gather<U>(c, op, L, cur, 0, nz);
       }
+      // three separate float32 passes in the reference (sample *= g; noise *= g; sample += noise)
+      if (op.ln > 0) {
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (cur[u] >= 0 && cur[u] < L && ln > 0) v[u] = add_rn(mul_rn(v[u], op.ra), mul_rn(nz[u], op.rb));
+        for (int u = 0; u < U; ++u)
+          if (cur[u] >= 0 && cur[u] < L) v[u] = add_rn(mul_rn(v[u], op.ra), mul_rn(nz[u], op.rb));
+      }
     } else if (op.kind == WFE_AUG_AFFINE) {
 #pragma unroll
       for (int u = 0; u < U; ++u)
         if (cur[u] >= 0 && cur[u] < L) v[u] = div_rn(sub_rn(v[u], op.ra), op.rb);
     }
   }
+}
+template <int U>
+__device__ __forceinline__ void seg_apply(const Chain& c, int lo, int hi, int L, int (&cur)[U], float (&v)[U]) {
+  float none[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) none[u] = 0.f;
+  seg_apply<U>(c, lo, hi, L, cur, v, -1, none);
+}
+
+// source samples at cur[u], then ops [lo, hi): the gathers of the segment's first NOISE op go
+// out BEFORE the source samples are waited for (its indices depend on positions only), so a
+// batch costs one memory round trip, not two.
+template <int U>
+__device__ __forceinline__ void seg_gather_apply(const Chain& c, int lo, int hi, int L, int (&cur)[U], float (&v)[U]) {
+  int k_pre = -1, back = 0;
+  for (int k = lo; k < hi; ++k) {
+    const COp op = get_cop(c, k);
+    if (op.kind == WFE_AUG_NOISE) {
+      k_pre = k;
+      break;
+    }
+    if (op.kind == WFE_AUG_SHIFT) back += op.i0;
+  }
+  float nz[U];
+  if (k_pre >= 0) {
+    noise_gather<U>(c, get_cop(c, k_pre), L, cur, back, nz);
+  } else {
+#pragma unroll
+    for (int u = 0; u < U; ++u) nz[u] = 0.f;
+  }
+  c.src.gather<U>(cur, L, v);
+  seg_apply<U>(c, lo, hi, L, cur, v, k_pre, nz);
 }
 
 // index into the (truncated, zero-padded, reflect-padded) utterance of staging
@@ -395,31 +480,205 @@ __device__ __forceinline__ double speed_pos(const Chain& c, int i) {
   return (i == c.len1 - 1) ? (double)c.len0 : mul_rn((double)i, c.step);
 }
 
+// Diagnostic builds (-DWFE_STAMPS): cycles spent in up to four parts of the staging, summed
+// over the batches of one tile.  Empty in the shipped library.
+struct Ticker {
+#ifdef WFE_STAMPS
+  unsigned long long prev, acc[4];
+  int batches;
+  __device__ __forceinline__ void start() {
+    acc[0] = acc[1] = acc[2] = acc[3] = 0;
+    batches = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prev)::"memory");
+  }
+  __device__ __forceinline__ void tick(int k) {
+    unsigned long long t_;
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+    acc[k] += t_ - prev;
+    prev = t_;
+  }
+  __device__ __forceinline__ void batch() { ++batches; }
+#else
+  __device__ __forceinline__ void start() {}
+  __device__ __forceinline__ void tick(int) {}
+  __device__ __forceinline__ void batch() {}
+#endif
+};
+
+// ---- the shipped chain shape, straight-line.  configs/augmentation.json orders its entries
+// noise -> speed -> shift -> volume, so every chain the reference's own configuration can draw
+// is [NOISE]? [SPEED]? then at most one SHIFT and one VOLUME (those two commute exactly: the
+// gain is positive).  For that shape the whole evaluation is unrolled without the op loop of
+// seg_apply (whose switch costs ~25 register moves per op and element): absent SHIFT / VOLUME
+// are the exact identities shift 0 / gain 1.0f.  Any other order takes the generic evaluator
+// below; both produce the same bits (tests: chain orders).
+struct Shipped {
+  bool ok;
+  int noise_k, shift;
+  float gain;
+};
+__device__ inline Shipped match_shipped(const Chain& c) {
+  Shipped f;
+  f.ok = c.cops != nullptr;
+  f.noise_k = -1;
+  f.shift = 0;
+  f.gain = 1.0f;
+  int n_shift = 0, n_vol = 0;
+  for (int k = 0; k < c.n_ops && f.ok; ++k) {
+    const COp op = get_cop(c, k);
+    const bool before_speed = c.speed_at >= 0 && k < c.speed_at;
+    const bool after_speed = c.speed_at >= 0 && k > c.speed_at;
+    if (op.kind == WFE_AUG_NOISE) {
+      if (f.noise_k >= 0 || n_shift || n_vol || after_speed || op.ln <= 0) f.ok = false;
+      f.noise_k = k;
+    } else if (op.kind == WFE_AUG_SHIFT) {
+      if (n_shift++ || before_speed) f.ok = false;
+      f.shift = op.i0;
+    } else if (op.kind == WFE_AUG_VOLUME) {
+      if (n_vol++ || before_speed) f.ok = false;
+      f.gain = op.f0;
+    } else if (op.kind != WFE_AUG_SPEED) {
+      f.ok = false;
+    }
+  }
+  return f;
+}
+
+template <bool SPEED, bool NOISE, int U>
+__device__ __forceinline__ void stage_shipped(const Chain& c, const Shipped f, float* __restrict__ lds, int p0, int n,
+                                              int len, int tid, Ticker& tk) {
+  constexpr int G = SPEED ? 2 * U : U;          // source samples per batch: both np.interp neighbours
+  const int L0 = c.len0, last = L0 - 1;
+  const int L1 = SPEED ? c.len1 : L0;
+  COp nop = get_cop(c, NOISE ? f.noise_k : 0);
+  const float* __restrict__ clip = c.noise + (NOISE ? nop.o0 : 0);
+  const bool wrap = nop.ln < L0;
+  // tile without reflection or padding: position q is sample p0 + q - 200
+  const bool plain = p0 - kHalf >= 0 && p0 - kHalf + kBlockSamples <= len;
+  if (L0 <= 0) {                                  // empty utterance: the chain of nothing is silence
+    for (int q = tid; q < kBlockSamples; q += 256) lds[pad_q(q)] = 0.f;
+    return;
+  }
+  for (int q0 = tid; q0 < kBlockSamples; q0 += 256 * U) {
+    int cur[U], idx[G];
+    bool in[U];
+    double fr[U];
+    if (plain) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) cur[u] = (q0 + 256 * u < kBlockSamples) ? p0 + q0 + 256 * u - kHalf + f.shift : kDeadIndex;
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = padded_index(q0 + 256 * u, p0, n, len);
+        cur[u] = i >= 0 ? i + f.shift : kDeadIndex;
+      }
+    }
+    // np.interp(np.linspace(0, len0, len1), arange(len0), seg0): position cur * step, clamped to the
+    // last sample (np.interp right of xp[-1] returns fp[-1]; linspace's exact last point len0 lands
+    // there too, and step is 0 for a one-sample result) -- then the fraction is 0 and j + 1 unused
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      in[u] = cur[u] >= 0 && cur[u] < L1;      // outside: the zero fill of the shift / beyond the signal
+      if (SPEED) {
+        const double pos = fmin(mul_rn((double)(in[u] ? cur[u] : 0), c.step), (double)last);
+        const int j = (int)pos;
+        fr[u] = pos - (double)j;
+        idx[2 * u] = j;
+        idx[2 * u + 1] = min(j + 1, last);
+      } else {
+        idx[u] = in[u] ? cur[u] : 0;
+      }
+    }
+    tk.tick(0);
+    // the noise gathers go out before the source samples are waited for: one round trip per batch
+    float nz[G];
+    if (NOISE) {
+      int m[G];
+      if (wrap) {                                 // np.pad(noise, 'wrap'): idx % ln without the integer divide
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          if (SPEED && (g & 1)) {                 // the right neighbour: one step on from the left one
+            const int nx = (m[g - 1] + 1 == nop.ln) ? 0 : m[g - 1] + 1;
+            m[g] = (idx[g] == idx[g - 1]) ? m[g - 1] : nx;
+          } else {
+            const int qd = (int)((double)idx[g] * nop.inv);
+            int r = idx[g] - qd * nop.ln;
+            r = (r < 0) ? r + nop.ln : r;
+            m[g] = (r >= nop.ln) ? r - nop.ln : r;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g) m[g] = idx[g] + nop.i1;
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) nz[g] = clip[min(max(m[g], 0), nop.ln - 1)];
+    }
+    float x[G];
+    c.src.load<G>(idx, x);                        // (indices are valid by construction; L0 > 0)
+    tk.tick(1);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float v;
+      if (SPEED) {
+        float s0 = x[2 * u], s1 = x[2 * u + 1];
+        if (NOISE) {                              // sample *= gain; noise *= gain; sample += noise: three roundings
+          s0 = add_rn(mul_rn(s0, nop.ra), mul_rn(nz[2 * u], nop.rb));
+          s1 = add_rn(mul_rn(s1, nop.ra), mul_rn(nz[2 * u + 1], nop.rb));
+        }
+        const double a0 = (double)s0, a1 = (double)s1;
+        const float mid = (float)add_rn(mul_rn(sub_rn(a1, a0), fr[u]), a0);
+        v = (fr[u] == 0.0) ? s0 : mid;
+      } else {
+        v = x[u];
+        if (NOISE) v = add_rn(mul_rn(v, nop.ra), mul_rn(nz[u], nop.rb));
+      }
+      v = mul_rn(in[u] ? v : 0.f, f.gain);
+      const int q = q0 + 256 * u;
+      if (q < kBlockSamples) lds[pad_q(q)] = v;
+    }
+    tk.tick(2);
+    tk.batch();
+  }
+}
+
 // Stages the augmented padded signal of one workgroup into the LDS image.
 // aux: AUXF floats of LDS free during staging (the seg0 buffer of SPEED chains).
 template <int AUXF>
-__device__ inline void stage_augmented(const Chain& c, float* __restrict__ lds, float* __restrict__ aux, int p0, int n,
+__device__ __forceinline__ void stage_augmented(const Chain& c, float* __restrict__ lds, float* __restrict__ aux, int p0, int n,
                                        int len, int tid, unsigned long long* st = nullptr) {
+  Ticker tk;
+  tk.start();
+  auto report = [&]() {
 #ifdef WFE_STAMPS
-  unsigned long long tA = 0, tW = 0, tB = 0, np_ = 0, t_prev = 0;
-  auto tick = [&](unsigned long long& acc) {
-    unsigned long long t_;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
-    acc += t_ - t_prev;
-    t_prev = t_;
-  };
-  { unsigned long long z = 0; tick(z); }
-  if (st) st[8] = st[9] = st[10] = st[11] = 0;
-#define WFE_TICK(acc) tick(acc)
-#else
-#define WFE_TICK(acc) do {} while (0)
+    if (st) {
+      st[8] = tk.acc[0];
+      st[9] = tk.acc[1];
+      st[10] = tk.acc[2];
+      st[11] = tk.batches;
+    }
 #endif
+  };
   if (!c.cops) {                                // more than kMaxCops ops: per-position evaluation from global memory
     for (int q = tid; q < kBlockSamples; q += 256) {
       const int i = padded_index(q, p0, n, len);
       lds[pad_q(q)] = i >= 0 ? chain_eval(c, c.n_ops, i) : 0.f;
     }
     return;
+  }
+  {
+    const Shipped f = match_shipped(c);
+    if (f.ok) {
+      if (c.speed_at >= 0) {
+        if (f.noise_k >= 0) stage_shipped<true, true, 14>(c, f, lds, p0, n, len, tid, tk);
+        else stage_shipped<true, false, 14>(c, f, lds, p0, n, len, tid, tk);
+      } else {
+        if (f.noise_k >= 0) stage_shipped<false, true, 21>(c, f, lds, p0, n, len, tid, tk);
+        else stage_shipped<false, false, 21>(c, f, lds, p0, n, len, tid, tk);
+      }
+      report();
+      return;
+    }
   }
   if (c.speed_at < 0) {
     // 41 positions per thread in 2 batches of 21: each batch pays one HBM round trip for the raw
@@ -437,8 +696,7 @@ __device__ inline void stage_augmented(const Chain& c, float* __restrict__ lds, 
         ok[u] = i >= 0;
         cur[u] = ok[u] ? i + S : kDeadIndex;
       }
-      c.src.gather<U>(cur, c.len0, v);
-      seg_apply<U>(c, 0, c.n_ops, c.len0, cur, v);
+      seg_gather_apply<U>(c, 0, c.n_ops, c.len0, cur, v);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int q = q0 + 256 * u;
@@ -476,9 +734,8 @@ __device__ inline void stage_augmented(const Chain& c, float* __restrict__ lds, 
       cur0[2 * u] = in ? j + S0 : kDeadIndex;
       cur0[2 * u + 1] = in ? (j < last ? j + 1 : last) + S0 : kDeadIndex;
     }
-    c.src.gather<2 * U>(cur0, c.len0, v0);
-    seg_apply<2 * U>(c, 0, c.speed_at, c.len0, cur0, v0);
-    WFE_TICK(tA);
+    seg_gather_apply<2 * U>(c, 0, c.speed_at, c.len0, cur0, v0);
+    tk.tick(1);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const double a0 = (double)v0[2 * u], a1 = (double)v0[2 * u + 1];
@@ -491,19 +748,10 @@ __device__ inline void stage_augmented(const Chain& c, float* __restrict__ lds, 
       const int q = q0 + 256 * u;
       if (q < kBlockSamples) lds[pad_q(q)] = ok[u] ? v[u] : 0.f;
     }
-    WFE_TICK(tB);
-#ifdef WFE_STAMPS
-    ++np_;
-#endif
+    tk.tick(2);
+    tk.batch();
   }
-#ifdef WFE_STAMPS
-  if (st) {
-    st[8] = tA;
-    st[9] = tW;
-    st[10] = tB;
-    st[11] = np_;
-  }
-#endif
+  report();
 }
 
 // ------------------------------------------------------------- kernel 1
