@@ -52,6 +52,9 @@ constexpr int kStampRow = 16;   // 0..5 phase boundaries, 6/7 stagger + k-loop w
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x3 = __attribute__((ext_vector_type(3))) float;
+// two consecutive floats at any 4-byte boundary: one global_load_dwordx2 (the memory pipe
+// spends ~16 cycles per wave on ANY per-lane-addressed load, so fewer, wider loads)
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
 
 // The 7 twiddles (one per bin tile) a lane needs per GEMM and k-step.  The table
 // stores 8 (two float4) but the 8th is padding: it is fetched as float4 + float3
@@ -555,6 +558,9 @@ __device__ __forceinline__ void stage_shipped(const Chain& c, const Shipped f, f
   const bool wrap = nop.ln < L0;
   // tile without reflection or padding: position q is sample p0 + q - 200
   const bool plain = p0 - kHalf >= 0 && p0 - kHalf + kBlockSamples <= len;
+  // float32 source of >= 2 samples (and a clip of >= 2): neighbours fetched as pairs
+  const bool pairs = SPEED && c.src.w && L0 >= 2 && (!NOISE || nop.ln >= 2);
+  const float clip0 = NOISE ? clip[0] : 0.f;
   if (L0 <= 0) {                                  // empty utterance: the chain of nothing is silence
     for (int q = tid; q < kBlockSamples; q += 256) lds[pad_q(q)] = 0.f;
     return;
@@ -591,31 +597,72 @@ __device__ __forceinline__ void stage_shipped(const Chain& c, const Shipped f, f
     }
     tk.tick(0);
     // the noise gathers go out before the source samples are waited for: one round trip per batch
-    float nz[G];
-    if (NOISE) {
-      int m[G];
-      if (wrap) {                                 // np.pad(noise, 'wrap'): idx % ln without the integer divide
+    float nz[G], x[G];
+    if (SPEED && pairs) {
+      // both np.interp neighbours in ONE load per lane: the pair starts at min(j, last - 1); at
+      // the last sample the right neighbour is not used (fraction 0).  Noise alike, with the
+      // clip's first sample (uniform) as the right neighbour where the wrap falls between the two.
+      f32x2u np_[U], xp[U];
+      bool nhi[U];
+      if (NOISE) {
+        int m0[U];
+        if (wrap) {                                 // (uniform: outside the unrolled loop)
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-          if (SPEED && (g & 1)) {                 // the right neighbour: one step on from the left one
-            const int nx = (m[g - 1] + 1 == nop.ln) ? 0 : m[g - 1] + 1;
-            m[g] = (idx[g] == idx[g - 1]) ? m[g - 1] : nx;
-          } else {
-            const int qd = (int)((double)idx[g] * nop.inv);
-            int r = idx[g] - qd * nop.ln;
+          for (int u = 0; u < U; ++u) {
+            const int qd = (int)((double)idx[2 * u] * nop.inv);
+            int r = idx[2 * u] - qd * nop.ln;
             r = (r < 0) ? r + nop.ln : r;
-            m[g] = (r >= nop.ln) ? r - nop.ln : r;
+            m0[u] = (r >= nop.ln) ? r - nop.ln : r;
           }
-        }
-      } else {
+        } else {
 #pragma unroll
-        for (int g = 0; g < G; ++g) m[g] = idx[g] + nop.i1;
+          for (int u = 0; u < U; ++u) m0[u] = idx[2 * u] + nop.i1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int mc = min(max(m0[u], 0), nop.ln - 1);
+          const int mb = min(mc, nop.ln - 2);
+          nhi[u] = mc > mb;
+          np_[u] = *reinterpret_cast<const f32x2u*>(clip + mb);
+        }
       }
 #pragma unroll
-      for (int g = 0; g < G; ++g) nz[g] = clip[min(max(m[g], 0), nop.ln - 1)];
+      for (int u = 0; u < U; ++u) xp[u] = *reinterpret_cast<const f32x2u*>(c.src.w + min(idx[2 * u], last - 1));
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool xhi = idx[2 * u] == last;
+        x[2 * u] = xhi ? xp[u].y : xp[u].x;
+        x[2 * u + 1] = xp[u].y;
+        if (NOISE) {
+          nz[2 * u] = nhi[u] ? np_[u].y : np_[u].x;
+          nz[2 * u + 1] = nhi[u] ? clip0 : np_[u].y;
+        }
+      }
+    } else {
+      if (NOISE) {
+        int m[G];
+        if (wrap) {                                 // np.pad(noise, 'wrap'): idx % ln without the integer divide
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            if (SPEED && (g & 1)) {                 // the right neighbour: one step on from the left one
+              const int nx = (m[g - 1] + 1 == nop.ln) ? 0 : m[g - 1] + 1;
+              m[g] = (idx[g] == idx[g - 1]) ? m[g - 1] : nx;
+            } else {
+              const int qd = (int)((double)idx[g] * nop.inv);
+              int r = idx[g] - qd * nop.ln;
+              r = (r < 0) ? r + nop.ln : r;
+              m[g] = (r >= nop.ln) ? r - nop.ln : r;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int g = 0; g < G; ++g) m[g] = idx[g] + nop.i1;
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) nz[g] = clip[min(max(m[g], 0), nop.ln - 1)];
+      }
+      c.src.load<G>(idx, x);                        // (indices are valid by construction; L0 > 0)
     }
-    float x[G];
-    c.src.load<G>(idx, x);                        // (indices are valid by construction; L0 > 0)
     tk.tick(1);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -671,10 +718,10 @@ __device__ __forceinline__ void stage_augmented(const Chain& c, float* __restric
     if (f.ok) {
       if (c.speed_at >= 0) {
         if (f.noise_k >= 0) stage_shipped<true, true, 14>(c, f, lds, p0, n, len, tid, tk);
-        else stage_shipped<true, false, 14>(c, f, lds, p0, n, len, tid, tk);
+        else stage_shipped<true, false, 21>(c, f, lds, p0, n, len, tid, tk);
       } else {
-        if (f.noise_k >= 0) stage_shipped<false, true, 21>(c, f, lds, p0, n, len, tid, tk);
-        else stage_shipped<false, false, 21>(c, f, lds, p0, n, len, tid, tk);
+        if (f.noise_k >= 0) stage_shipped<false, true, 41>(c, f, lds, p0, n, len, tid, tk);
+        else stage_shipped<false, false, 41>(c, f, lds, p0, n, len, tid, tk);
       }
       report();
       return;
