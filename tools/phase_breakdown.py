@@ -61,7 +61,7 @@ print(f"{'total':22s} median {np.median(tot):9.0f}  p10 {np.percentile(tot, 10):
 
 if os.environ.get("WFE_PHASE_AUG") == "1":           # slots 8..11 carry the staging passes of SPEED chains
     t0, t1, t2, nb = s[:, 8], s[:, 9], s[:, 10], s[:, 11]
-    for nme, sel in (("3-batch tiles (SPEED)", nb >= 3), ("2-batch tiles", nb == 2)):
+    for nme, sel in (("tiles staged in >= 3 batches (SPEED)", nb >= 3), ("tiles staged in 2 batches", nb == 2), ("tiles staged in 1 batch", nb == 1)):
         if not sel.any():
             continue
         print(f"{nme}: {sel.sum()} of {len(s)} waves; staging phase median {np.median(d[sel, 0]):.0f}")

@@ -12,7 +12,7 @@ out = ["Additional workloads: rocprofv3 --kernel-trace --stats of `python3 bench
        "(MI355X, batch 256 x 30 s)", ""]
 for w, flags in (("aug", "--augment   (BASELINE config 3)"), ("mel128", "--n-mel 128"),
                  ("speech", "--lengths speech   (utterances 1..15 s padded to 30 s)")):
-    f = glob.glob(f"{root}/{w}/vm/*kernel_stats.csv")[0]
+    f = glob.glob(f"{root}/{w}/*/*kernel_stats.csv")[0]
     out.append(f"== bench.py {flags}")
     j = json.loads([l for l in open(f"{root}/{w}.log") if l.startswith("{")][-1])
     out.append(f'   bench line: value {j["value"]:.1f} {j["unit"]}, ms_per_step {j["ms_per_step"]:.4f}, kernel 1 '

@@ -804,7 +804,7 @@ __device__ __forceinline__ void stage_augmented(const Chain& c, float* __restric
 // ------------------------------------------------------------- kernel 1
 template <int NMT, bool POWER, bool AUG, int BANK>
 __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
-  constexpr bool STAGGER = !POWER;
+  constexpr bool STAGGER = !POWER && !AUG;       // (AUG tiles differ in length by themselves: the sleep cost 1 %)
   // waveform image | twiddle slots, reused as the output tile after the k-loop
   constexpr int kAuxFloats = (16 * NMT * kTileStride > 2 * kDftStepFloats) ? 16 * NMT * kTileStride : 2 * kDftStepFloats;
   __shared__ __attribute__((aligned(16))) float lds[kLdsWaveFloats + kAuxFloats];
