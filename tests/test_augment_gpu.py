@@ -166,9 +166,10 @@ def test_do_normalize_affine(fe, golden_logmel):
     ("noise", "volume", "noise2"),
 ])
 def test_other_chain_orders(fe, order):
-    """The kernels evaluate any order of ops around (at most) one speed op: the
-    staged evaluator (two passes through LDS for speed chains) against the CPU
-    oracle, which was pinned on the reference's augment() for the shipped order."""
+    """The kernels evaluate any order of ops around (at most) one speed op: these orders
+    take the generic op-major evaluator (the shipped order has a straight-line one),
+    checked against the CPU oracle, which was pinned on the reference's augment() for the
+    shipped order."""
     from wfe_amd.frontend import NoiseBank, pack_ragged
     from wfe_amd.augment import AugmentPlanner
     entry = {
@@ -213,9 +214,9 @@ def test_other_chain_orders(fe, order):
 
 @pytest.mark.parametrize("rate", [0.31, 2.9, 7.5, 33.0])
 def test_extreme_speed_rates(fe, rate):
-    """Rates far outside the shipped 0.9..1.1: the source span of a staging pass
-    no longer fits the LDS buffer in one piece (more, smaller passes) and, above
-    ~20x, not at all (per-position evaluation).  Bit-exact against the oracle."""
+    """Rates far outside the shipped 0.9..1.1 (both interpolation neighbours are fetched
+    per output position, so the rate is not limited by any buffer).  Bit-exact against
+    the oracle."""
     from wfe_amd import _lib
     w = cases.bench_clip(77, 300000)
     want = oa.change_speed(w.copy(), rate)
