@@ -227,6 +227,50 @@ def test_extreme_speed_rates(fe, rate):
     assert not got[0, k:].any()
 
 
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 161, 4000])
+def test_shipped_shape_tiny_inputs(fe, n):
+    """The straight-line evaluator of the shipped chain shape at its edges: utterances of
+    1..5 samples (the pair loads need two), noise clips of 1, 2 and 7 samples (wrap inside a
+    pair) and clips longer than the utterance, with and without a speed op.  Speed-only chains
+    bit-exact, noise chains to the gain tolerance, against the oracle."""
+    from wfe_amd import _lib
+    x = (0.1 * np.random.default_rng(3000 + n).standard_normal(n)).astype(np.float32) + np.float32(0.01)
+    bank = [np.float32([0.03]), np.float32([0.02, -0.05]),
+            (0.05 * np.random.default_rng(5).standard_normal(7)).astype(np.float32),
+            (0.05 * np.random.default_rng(6).standard_normal(4100)).astype(np.float32)]
+    waves, plans, want, exact = [], [], [], []
+    for rate in (0.9, 1.1, 2.0):
+        if int(n / rate) < 1:
+            continue
+        waves.append(x)
+        plans.append([(_lib.AUG_SPEED, int(n / rate), 0, 0, 0.0), (_lib.AUG_VOLUME, 0, 0, 3, float(np.float32(10. ** (3 / 20.))))])
+        want.append(oa.volume(oa.change_speed(x.copy(), rate), 3))
+        exact.append(True)
+    for j, clip in enumerate(bank):
+        for rate in (None, 0.9, 1.1):
+            if rate is not None and int(n / rate) < 1:
+                continue
+            start = min(17, len(clip) - n) if len(clip) > n else 0
+            y = oa.add_noise(x.copy(), clip, 20, lambda a, b: start)       # noqa: B023
+            ops = [(_lib.AUG_NOISE, j, start, 20, 0.0)]
+            if rate is not None:
+                y = oa.change_speed(y, rate)
+                ops.append((_lib.AUG_SPEED, int(n / rate), 0, 0, 0.0))
+            waves.append(x)
+            plans.append(ops)
+            want.append(y)
+            exact.append(False)
+    got, got_len = _run_wave(fe, waves, plans, bank, n_samples=12000)
+    for i, w in enumerate(want):
+        assert got_len[i] == len(w), (i, plans[i])
+        err = np.abs(got[i, :len(w)] - w).max()
+        if exact[i]:
+            assert err == 0.0, (i, plans[i], err)
+        else:
+            assert err <= 2 * NOISE_RTOL * max(np.abs(w).max(), 1e-30), (i, plans[i], err)
+        assert not got[i, len(w):].any()
+
+
 def _rir(seed, n):
     """A synthetic room impulse response: direct path + exponentially decaying noise."""
     rng = np.random.default_rng(seed)
