@@ -153,6 +153,9 @@ def main() -> None:
                          "configs/augmentation.json with the probabilities of noise / speed / shift / volume forced "
                          "to 1.0 (shipped: 0.5 / 0 / 0 / 0 and a placeholder noise dir), decisions drawn on the host "
                          "with random.seed(0) in the reference's order, noise bank = 16 synthetic 10 s clips")
+    ap.add_argument("--out-dtype", choices=["float32", "float16", "bfloat16"], default="float32",
+                    help="element type of the log-mel output (float32 = the reference's; the 16-bit types are "
+                         "that result rounded to nearest even, SURVEY 8f N4).  Not the headline configuration")
     ap.add_argument("--shard-clips", type=int, default=0,
                     help="BASELINE config 4 instead of the default workload: this many clips in all, contiguous "
                          "shards per rank (wfe_amd.sharded), batches of --batch; use with --n-mel 128")
@@ -180,7 +183,8 @@ def main() -> None:
     if args.lengths == "speech":
         rs = np.random.default_rng(99 + rank)
         lens = torch.from_numpy(rs.integers(SR, 15 * SR, size=args.batch).astype(np.int32)).to(device)
-    out = torch.empty((args.batch, args.n_mel, N_SAMPLES // 160), dtype=torch.float32, device=device)
+    fe.set_output_dtype(getattr(torch, args.out_dtype))
+    out = torch.empty((args.batch, args.n_mel, N_SAMPLES // 160), dtype=fe.out_dtype, device=device)
     if args.pcm16:
         wav = torch.clamp(torch.round(wav * 32768.0), -32768, 32767).to(torch.int16)
 
@@ -302,7 +306,8 @@ def main() -> None:
             "config": {"workload": f"whisper-small {args.n_mel}-mel front end, batch {args.batch} synthetic 30 s "
                                    f"16 kHz clips per GPU, {aug_note}, input resident in HBM"
                                    + ("" if args.lengths == "full" else "; utterances 1..15 s padded to 30 s")
-                                   + ("; 16-bit PCM input converted on the GPU" if args.pcm16 else ""),
+                                   + ("; 16-bit PCM input converted on the GPU" if args.pcm16 else "")
+                                   + ("" if args.out_dtype == "float32" else f"; output rounded to {args.out_dtype}"),
                        "batch_per_gpu": args.batch, "n_mel": args.n_mel, "clip_seconds": 30,
                        "parallelism": f"dp{world} (utterances sharded, no data-path collective)"},
             "clips_per_sec": clips / elapsed,

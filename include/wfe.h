@@ -187,6 +187,19 @@ int wfe_augment_waveform(wfe_handle h, const float* wav, const int64_t* offsets,
 int wfe_power_spectrum(wfe_handle h, const float* wav, const int64_t* offsets, const int32_t* lengths,
                        int64_t row_stride, int32_t batch, int32_t n_samples, float* out, void* stream);
 
+/* ---- output element type ---------------------------------------------------- */
+/* No reference counterpart: the reference's extractor returns float32 and the
+ * Trainer casts input_features to the training dtype on the device (fp16=True,
+ * finetune.py:122).  With WFE_OUT_F16 / WFE_OUT_BF16 the log-mel
+ * entry points (wfe_logmel, wfe_augment_logmel, wfe_logmel_pcm16) write that
+ * dtype directly -- `out` then points to batch * n_mel * (n_samples / 160) 2-byte
+ * elements -- and the values are bit for bit the float32 result rounded to
+ * nearest even (the clamp of kernel 2 commutes with the rounding).  The setting
+ * belongs to the handle and stays until changed; wfe_power_spectrum and
+ * wfe_augment_waveform are always float32. */
+typedef enum { WFE_OUT_F32 = 0, WFE_OUT_F16 = 1, WFE_OUT_BF16 = 2 } wfe_out_format;
+int wfe_set_output_format(wfe_handle h, int32_t format);
+
 /* ---- measurement ---------------------------------------------------------- */
 /* No reference counterpart (the reference has no timing code).
  * When enabled, every front-end launch is bracketed by HIP events on the

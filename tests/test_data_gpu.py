@@ -171,3 +171,28 @@ def test_other_sampling_rates_end_to_end(tmp_path):
     err = np.abs(got - ol.logmel_f32(want, n_mel=80)).reshape(len(recs), -1).max(axis=1)
     print("multi-rate augmented max-abs-err:", err)
     assert (err <= 1e-4).all(), err
+
+
+def test_collator_output_dtype(tmp_path):
+    """output_dtype / WFE_OUTPUT_DTYPE: input_features arrive in the training dtype and equal
+    the float32 batch rounded; the shared front end is float32 again afterwards."""
+    from wfe_amd import data as wd
+    rng = np.random.default_rng(31)
+    recs = []
+    for i, dur in enumerate([1.2, 3.4, 0.6]):
+        p = tmp_path / f"a{i}.wav"
+        _write_wav(p, 0.1 * rng.standard_normal(int(dur * 16000)))
+        recs.append({"audio": {"path": str(p)}, "sentence": f"utt {i}", "duration": dur})
+    mf = tmp_path / "list.json"
+    mf.write_text("\n".join(json.dumps(r) for r in recs))
+    proc = stubs.StubProcessor(n_mel=80)
+    ds = wd.CustomDataset(str(mf), proc)
+    items = [ds[i] for i in range(3)]
+    want = wd.DataCollatorSpeechSeq2SeqWithPadding(processor=proc)(items)["input_features"]
+    for name in ("float16", "bfloat16"):
+        got = wd.DataCollatorSpeechSeq2SeqWithPadding(processor=proc, output_dtype=name)(items)["input_features"]
+        assert got.dtype == getattr(torch, name) and torch.equal(got, want.to(got.dtype))
+    again = wd.DataCollatorSpeechSeq2SeqWithPadding(processor=proc)(items)["input_features"]
+    assert again.dtype == torch.float32 and torch.equal(again, want)
+    with pytest.raises(ValueError):
+        wd.DataCollatorSpeechSeq2SeqWithPadding(processor=proc, output_dtype="int8")

@@ -45,6 +45,7 @@ struct wfe_context {
   float* d_tile_stats = nullptr;            // per-tile minima / maxima of kernel 1, grows on demand
   size_t tile_stats_cap = 0;
   unsigned long long* d_stamps = nullptr;   // diagnostic builds only (wfe_debug_stamps)
+  int out_kind = WFE_OUT_F32;               // wfe_set_output_format
   std::string err;
 };
 
@@ -199,7 +200,11 @@ int run_frontend(wfe_context* h, const void* wav, int channels, const int64_t* o
     else if (a.pcm) a.pcm += (long long)s.begin * row_stride;
     else a.wav += (long long)s.begin * row_stride;
     a.lengths += s.begin;
-    a.out = out + (long long)s.begin * per_clip;
+    // (16-bit log-mel output: `out` counts 2-byte elements)
+    const int kind = (mode == 0) ? h->out_kind : WFE_OUT_F32;
+    a.out = (kind == WFE_OUT_F32) ? out + (long long)s.begin * per_clip
+                                   : reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(out) + (long long)s.begin * per_clip);
+    a.out_kind = kind;
     if (aug) {
       a.ops = ops;
       a.op_begin = op_begin + s.begin;
@@ -228,7 +233,7 @@ int run_frontend(wfe_context* h, const void* wav, int channels, const int64_t* o
     HIP_TRY(h, wfe::launch_frontend(a, s.count, mode, aug, h->bank, stream));
     if (ev) HIP_TRY(h, hipEventRecord(ev[1], stream));
     if (mode == 0)
-      HIP_TRY(h, wfe::launch_clamp(a.out, h->d_tile_stats, s.count, h->cfg.n_mel, T, stream));
+      HIP_TRY(h, wfe::launch_clamp(a.out, kind, h->d_tile_stats, s.count, h->cfg.n_mel, T, stream));
     if (ev) HIP_TRY(h, hipEventRecord(ev[2], stream));
   }
   return WFE_OK;
@@ -324,6 +329,14 @@ int wfe_debug_stamps(wfe_handle h, unsigned long long* device_buf) {
   return WFE_OK;
 }
 #endif
+
+int wfe_set_output_format(wfe_handle h, int32_t format) {
+  if (!h) return WFE_ERR_ARG;
+  if (format != WFE_OUT_F32 && format != WFE_OUT_F16 && format != WFE_OUT_BF16)
+    return fail(h, WFE_ERR_ARG, "output format %d is not WFE_OUT_F32 / WFE_OUT_F16 / WFE_OUT_BF16", format);
+  h->out_kind = format;
+  return WFE_OK;
+}
 
 int wfe_kernel_timing(wfe_handle h, int32_t enable) {
   if (!h) return fail(nullptr, WFE_ERR_ARG, "null handle");

@@ -34,6 +34,7 @@ struct FrontArgs {
   unsigned mel_mask[14];
   // output
   float* out;                    // (B, n_mel, T) log10 mel power, or (B, 201, T) power
+  int out_kind;                  // log-mel element type: 0 float32, 1 float16, 2 bfloat16 (out then points to 2-byte elements)
   float* tile_stats;             // (B x 64-frame tiles x kTileStats): log10 mel minima [frame group 4][2], maxima [wave 4]
   unsigned* cu_tickets;          // (4096) arrival counters per CU, zeroed before the launch (stagger heuristic)
   // augmentation (AUG kernels only)
@@ -49,7 +50,8 @@ struct FrontArgs {
 // mode 0: log10 mel + clip max.  mode 1: power spectrum.
 hipError_t launch_frontend(const FrontArgs& a, int batch, int mode, bool augmented, int bank, hipStream_t stream);
 // max(stored, g(max-8)) over the tiles whose minimum is below max-8 (kernel 1 stored g(v) = (v+4)/4)
-hipError_t launch_clamp(float* out, const float* tile_stats, int batch, int n_mel, int n_frames, hipStream_t stream);
+hipError_t launch_clamp(float* out, int out_kind, const float* tile_stats, int batch, int n_mel, int n_frames,
+                        hipStream_t stream);
 // partial sums of squares of the noise clips: meansq has n_noise x kNoiseParts doubles
 constexpr int kNoiseParts = 16;
 hipError_t launch_noise_meansq(const float* noise, const long long* noise_off, int n_noise, double* meansq,

@@ -74,6 +74,21 @@ __device__ __forceinline__ Frag7 load_frag7(const f32x4* p) {
 }
 
 // ------------------------------------------------------------------ utilities
+// float32 -> the 16-bit output formats, round to nearest even (what torch's .half() /
+// .bfloat16() do), and back for kernel 2's comparison.  Values are finite here.
+__device__ __forceinline__ unsigned to16(float v, bool bf16) {
+  if (bf16) {
+    const unsigned u = __float_as_uint(v);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+  }
+  const _Float16 h = (_Float16)v;
+  return (unsigned)__builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ float from16(unsigned h, bool bf16) {
+  if (bf16) return __uint_as_float(h << 16);
+  return (float)__builtin_bit_cast(_Float16, (unsigned short)h);
+}
+
 // ---- single, un-contracted IEEE operations.  hipcc compiles device code with
 // -ffp-contract=fast and HIP's __fmul_rn / __fadd_rn are the plain operators, so
 // a * b + c written with them can still become one fma (it did: 5 % of the noise-mixed
@@ -1251,7 +1266,34 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   __syncthreads();
   float* __restrict__ lo = a.out + (long long)b * a.n_mel * T + t0;
   const int frames_here = (T - t0 < kBlockFrames) ? (T - t0) : kBlockFrames;
-  if ((T & 3) == 0 && (reinterpret_cast<uintptr_t>(lo) & 15u) == 0) {
+  if (a.out_kind != 0) {
+    // float16 / bfloat16 output (the encoder's input dtype under fp16 / bf16 training): the same
+    // rows, rounded once here -- rounding is monotone, so kernel 2's clamp commutes with it too
+    const bool bf = a.out_kind == 2;
+    unsigned short* __restrict__ lo16 = reinterpret_cast<unsigned short*>(a.out) + (long long)b * a.n_mel * T + t0;
+    if ((T & 3) == 0 && (reinterpret_cast<uintptr_t>(lo16) & 7u) == 0) {
+      constexpr int kIt = 16 * NMT / 16;
+      f32x4 row[kIt];
+#pragma unroll
+      for (int it = 0; it < kIt; ++it)
+        row[it] = *reinterpret_cast<const f32x4*>(tile + (it * 16 + (tid >> 4)) * kTileStride + 4 * (tid & 15));
+#pragma unroll
+      for (int it = 0; it < kIt; ++it) {
+        const int mel = it * 16 + (tid >> 4), c4 = tid & 15;
+        if (mel < a.n_mel && 4 * c4 < frames_here) {
+          uint2 pk;
+          pk.x = to16(row[it][0], bf) | (to16(row[it][1], bf) << 16);
+          pk.y = to16(row[it][2], bf) | (to16(row[it][3], bf) << 16);
+          *reinterpret_cast<uint2*>(lo16 + (long long)mel * T + 4 * c4) = pk;
+        }
+      }
+    } else {
+      for (int idx = tid; idx < a.n_mel * kBlockFrames; idx += 256) {
+        const int mel = idx >> 6, fb = idx & 63;
+        if (fb < frames_here) lo16[(long long)mel * T + fb] = (unsigned short)to16(tile[mel * kTileStride + fb], bf);
+      }
+    }
+  } else if ((T & 3) == 0 && (reinterpret_cast<uintptr_t>(lo) & 15u) == 0) {
     constexpr int kIt = 16 * NMT / 16;                  // (16 NMT rows x 16 float4) / 256 threads
     f32x4 row[kIt];
 #pragma unroll
@@ -1278,8 +1320,8 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
 // workgroups; g is monotone, so the result is max(stored, g(max - 8)) bit for bit, and
 // a workgroup's (n_mel x 64) tile needs touching only when its minimum is below
 // max - 8.  One workgroup here per workgroup of kernel 1: most exit after 5 loads.
-__global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ out, const float* __restrict__ tile_stats,
-                                                    int n_mel, int T) {
+__global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ out, int out_kind,
+                                                    const float* __restrict__ tile_stats, int n_mel, int T) {
   __shared__ float sh[4];
   const int b = blockIdx.y;
   const int nblk = gridDim.x;
@@ -1296,6 +1338,53 @@ __global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ out, con
   // decided per half tile (32 frames): two frame groups, each with the minima of its (up to two) waves
   const int tid = threadIdx.x;
   const float floor_g = (floor_v + 4.0f) * 0.25f;
+  if (out_kind != 0) {
+    // 16-bit output: max(h, round(floor)) on the stored halves == round(max(g(v), floor))
+    const bool bf = out_kind == 2;
+    unsigned short* __restrict__ p16 =
+        reinterpret_cast<unsigned short*>(out) + (long long)b * n_mel * T + blockIdx.x * kBlockFrames;
+    const bool vec16 = (T & 3) == 0 && (reinterpret_cast<uintptr_t>(p16) & 7u) == 0;
+    const unsigned hf = to16(floor_g, bf), hc = to16(fmaxf(-1.5f, floor_g), bf);
+    const float ff = from16(hf, bf);
+    for (int h = 0; h < 2; ++h) {
+      const float lowest = fminf(fminf(bm[4 * h], bm[4 * h + 1]), fminf(bm[4 * h + 2], bm[4 * h + 3]));
+      if (!(lowest < floor_v)) continue;
+      const int t0 = blockIdx.x * kBlockFrames + 32 * h;
+      if (t0 >= T) continue;
+      const int frames_here = (T - t0 < 32) ? (T - t0) : 32;
+      unsigned short* __restrict__ ph = p16 + 32 * h;
+      const bool silent = lowest == -INFINITY;
+      if (vec16) {
+        for (int idx = tid; idx < n_mel * 8; idx += 256) {
+          const int mel = idx >> 3, c4 = idx & 7;
+          if (4 * c4 < frames_here) {
+            uint2* q = reinterpret_cast<uint2*>(ph + (long long)mel * T + 4 * c4);
+            uint2 v;
+            v.x = v.y = hc | (hc << 16);
+            if (!silent) {
+              v = *q;
+              unsigned e[4] = {v.x & 0xffffu, v.x >> 16, v.y & 0xffffu, v.y >> 16};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) e[j] = (from16(e[j], bf) > ff) ? e[j] : hf;
+              v.x = e[0] | (e[1] << 16);
+              v.y = e[2] | (e[3] << 16);
+            }
+            *q = v;
+          }
+        }
+      } else {
+        for (int idx = tid; idx < n_mel * 32; idx += 256) {
+          const int mel = idx >> 5, fb = idx & 31;
+          if (fb < frames_here) {
+            unsigned short* q = ph + (long long)mel * T + fb;
+            const unsigned e = *q;
+            *q = (unsigned short)(silent ? hc : ((from16(e, bf) > ff) ? e : hf));
+          }
+        }
+      }
+    }
+    return;
+  }
   float* __restrict__ p = out + (long long)b * n_mel * T + blockIdx.x * kBlockFrames;
   const bool vec = (T & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
   for (int h = 0; h < 2; ++h) {
@@ -1736,9 +1825,10 @@ hipError_t launch_frontend(const FrontArgs& a, int batch, int mode, bool aug, in
   return aug ? launch_k1<8, false, true, 0>(a, batch, stream) : launch_k1<8, false, false, 0>(a, batch, stream);
 }
 
-hipError_t launch_clamp(float* out, const float* tile_stats, int batch, int n_mel, int n_frames, hipStream_t stream) {
+hipError_t launch_clamp(float* out, int out_kind, const float* tile_stats, int batch, int n_mel, int n_frames,
+                        hipStream_t stream) {
   const dim3 grid((n_frames + kBlockFrames - 1) / kBlockFrames, batch);
-  hipLaunchKernelGGL(clamp_kernel, grid, dim3(256), 0, stream, out, tile_stats, n_mel, n_frames);
+  hipLaunchKernelGGL(clamp_kernel, grid, dim3(256), 0, stream, out, out_kind, tile_stats, n_mel, n_frames);
   return hipGetLastError();
 }
 

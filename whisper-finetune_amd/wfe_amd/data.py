@@ -479,11 +479,20 @@ class DataCollatorSpeechSeq2SeqWithPadding:
     with_ids = False
 
     def __init__(self, processor: Any, device=None, device_output: Optional[bool] = None, noise_clips=None,
-                 noise_rates=None):
+                 noise_rates=None, output_dtype=None):
         self.processor = processor
         self.device = device
         self.device_output = (os.environ.get("WFE_DEVICE_OUTPUT", "0") == "1") if device_output is None \
             else bool(device_output)
+        # input_features in the training dtype straight from the kernels (fp16=True, finetune.py:122):
+        # the float32 result rounded to nearest even.  Default float32, like the reference's batches.
+        if output_dtype is None:
+            output_dtype = os.environ.get("WFE_OUTPUT_DTYPE", "float32")
+        if isinstance(output_dtype, str):
+            if output_dtype not in ("float32", "float16", "bfloat16"):
+                raise ValueError(f"WFE_OUTPUT_DTYPE / output_dtype {output_dtype!r} is not float32, float16 or bfloat16")
+            output_dtype = getattr(torch, output_dtype)
+        self.output_dtype = output_dtype
         self._clip_src = {"noise": (noise_clips, noise_rates)} if noise_clips is not None else None
         self._noise_banks: dict = {}
         self._packer = None
@@ -550,6 +559,20 @@ class DataCollatorSpeechSeq2SeqWithPadding:
         return fe.logmel(wav, lens, n_samples=n_samples, offsets=off, channels=ch)
 
     def _features(self, items):
+        if self.output_dtype == torch.float32:
+            return self._features_impl(items, None)
+        from .feature_extractor import front_end
+        fe = front_end(self.processor.feature_extractor.feature_size, self.device) \
+            if any("waveform" in it for it in items) else None
+        if fe is not None:
+            fe.set_output_dtype(self.output_dtype)       # the front end is shared with the feature extractor:
+        try:                                             # float32 again when this batch is done
+            return self._features_impl(items, fe).to(self.output_dtype)
+        finally:
+            if fe is not None:
+                fe.set_output_dtype(torch.float32)
+
+    def _features_impl(self, items, _fe):
         fe_cfg = self.processor.feature_extractor
         n_mel, n_samples = fe_cfg.feature_size, fe_cfg.n_samples
         frames = n_samples // fe_cfg.hop_length
@@ -588,7 +611,7 @@ class DataCollatorSpeechSeq2SeqWithPadding:
                 else:
                     out = fe.logmel(flat, lens, n_samples=n_samples, offsets=off, channels=ch)
             if staged:
-                whole = torch.empty((len(gpu_items), n_mel, frames), dtype=torch.float32, device=fe.device)
+                whole = torch.empty((len(gpu_items), n_mel, frames), dtype=fe.out_dtype, device=fe.device)
                 if simple:
                     whole[torch.tensor(simple, device=fe.device)] = out
                 for members in staged.values():
@@ -612,7 +635,7 @@ class DataCollatorSpeechSeq2SeqWithPadding:
             if feats[i] is None:
                 f = it["input_features"]
                 f = f if isinstance(f, torch.Tensor) else torch.from_numpy(np.asarray(f))
-                feats[i] = f.reshape(n_mel, -1).to(torch.float32)
+                feats[i] = f.reshape(n_mel, -1).to(self.output_dtype)
                 assert feats[i].shape[1] == frames
         return torch.stack(feats, dim=0)
 

@@ -69,6 +69,19 @@ class HipFrontEnd:
         h = C.c_void_p()
         _lib.check(_lib.lib().wfe_create(C.byref(cfg), C.byref(h)), None)
         self._h = h
+        self.out_dtype = torch.float32
+
+    _OUT_FORMATS = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}     # wfe_out_format
+
+    def set_output_dtype(self, dtype: torch.dtype) -> None:
+        """Element type of the log-mel output of logmel / augment_logmel: float32 (the
+        reference's), or float16 / bfloat16 = the float32 result rounded to nearest even,
+        written directly (the Trainer casts input_features to the training
+        dtype anyway, finetune.py:122)."""
+        if dtype not in self._OUT_FORMATS:
+            raise ValueError(f"output dtype {dtype} is not float32, float16 or bfloat16")
+        _lib.check(_lib.lib().wfe_set_output_format(self._h, self._OUT_FORMATS[dtype]), self._h)
+        self.out_dtype = dtype
 
     def close(self):
         if self._h is not None:
@@ -117,22 +130,26 @@ class HipFrontEnd:
         _lib.check(_lib.lib().wfe_kernel_times(self._h, C.byref(f), C.byref(c), C.byref(n)), self._h)
         return f.value, c.value, n.value
 
+    def _out(self, out, shape):
+        if out is None:
+            return torch.empty(shape, dtype=self.out_dtype, device=self.device)
+        if tuple(out.shape) != shape or out.dtype != self.out_dtype or not out.is_contiguous() \
+                or out.device != self.device:
+            raise ValueError(f"out must be a contiguous {self.out_dtype} {shape} tensor on {self.device}")
+        return out
+
     # ---------------------------------------------------------------- hot path
     def logmel(self, wav: torch.Tensor, lengths: torch.Tensor, n_samples: int = N_SAMPLES,
                offsets: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
                channels: int = 1) -> torch.Tensor:
-        """(B, n_mel, n_samples // 160) float32 on the device.  ``wav`` is (B, stride)
+        """(B, n_mel, n_samples // 160) float32 (or set_output_dtype's) on the device.  ``wav`` is (B, stride)
         or, with ``offsets``, a flat buffer of ragged utterances; float32 samples, or
         int16 PCM with ``channels`` interleaved channels (lengths in frames, offsets and
         stride in int16 elements), converted and mixed down on the device."""
         batch, stride = self._geometry(wav, lengths, offsets)
         self._check_inputs(wav, lengths, offsets, batch)
         shape = (batch, self.n_mel, n_samples // HOP)
-        if out is None:
-            out = torch.empty(shape, dtype=torch.float32, device=self.device)
-        elif tuple(out.shape) != shape or out.dtype != torch.float32 or not out.is_contiguous() \
-                or out.device != self.device:
-            raise ValueError(f"out must be a contiguous float32 {shape} tensor on {self.device}")
+        out = self._out(out, shape)
         if wav.dtype == torch.int16:
             _lib.check(_lib.lib().wfe_logmel_pcm16(
                 self._h, _ptr(wav), _ptr(offsets), _ptr(lengths), stride, int(channels), batch, int(n_samples),
@@ -243,8 +260,7 @@ class HipFrontEnd:
         if begin.numel() != batch + 1:
             raise ValueError("one op list per utterance")
         shape = (batch, self.n_mel, n_samples // HOP)
-        if out is None:
-            out = torch.empty(shape, dtype=torch.float32, device=self.device)
+        out = self._out(out, shape)
         tail = (_ptr(ops), _ptr(begin), total, _ptr(noise.data) if noise else None,
                 _ptr(noise.offsets) if noise else None, noise.n if noise else 0, _ptr(out), self._stream())
         if wav.dtype == torch.int16:
