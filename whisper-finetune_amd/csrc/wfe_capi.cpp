@@ -20,7 +20,6 @@ struct wfe_context {
   wfe_config cfg;
   float* d_dft = nullptr;
   float* d_mel = nullptr;
-  unsigned* d_tickets = nullptr;        // kCuTickets per-CU arrival counters (stagger heuristic of kernel 1)
   wfe::Resolved* d_resolved = nullptr;  // grows on demand
   size_t resolved_cap = 0;
   double* d_noise_meansq = nullptr;     // grows on demand
@@ -52,7 +51,6 @@ struct wfe_context {
 namespace {
 
 constexpr int kMaxBatchPerLaunch = 4096;
-constexpr int kCuTickets = 4096;          // per-CU arrival counters behind the clip maxima
 thread_local std::string g_create_err;
 
 int fail(wfe_context* h, int code, const char* fmt, ...) {
@@ -116,7 +114,6 @@ void fill_args(wfe_context* h, wfe::FrontArgs& a, const void* wav_or_pcm, int ch
   a.dft_tab = h->d_dft;
   a.mel_tab = h->d_mel;
   std::memcpy(a.mel_mask, h->mel_mask, sizeof a.mel_mask);
-  a.cu_tickets = h->d_tickets;
   a.tile_stats = h->d_tile_stats;
   a.stamps = h->d_stamps;
 }
@@ -214,9 +211,6 @@ int run_frontend(wfe_context* h, const void* wav, int channels, const int64_t* o
       a.resolved = h->d_resolved;
       HIP_TRY(h, wfe::launch_resolve(a, s.count, h->d_partials, stream));
     }
-    // the per-CU arrival tickets of kernel 1's stagger heuristic
-    if (mode == 0)
-      HIP_TRY(h, hipMemsetAsync(h->d_tickets, 0, sizeof(unsigned) * kCuTickets, stream));
     hipEvent_t* ev = nullptr;
     if (h->timing) {
       if (h->ev_used + 3 > h->ev_pool.size()) {
@@ -283,7 +277,6 @@ int wfe_create(const wfe_config* cfg, wfe_handle* out) {
   hipError_t e = guard.ok ? hipSuccess : hipErrorInvalidDevice;
   if (e == hipSuccess) e = hipMalloc(&h->d_dft, dft.size() * sizeof(float));
   if (e == hipSuccess) e = hipMalloc(&h->d_mel, mel.size() * sizeof(float));
-  if (e == hipSuccess) e = hipMalloc(&h->d_tickets, sizeof(unsigned) * kCuTickets);
   if (e == hipSuccess) e = hipMemcpy(h->d_dft, dft.data(), dft.size() * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(h->d_mel, mel.data(), mel.size() * sizeof(float), hipMemcpyHostToDevice);
   if (e != hipSuccess) {
@@ -300,7 +293,6 @@ int wfe_destroy(wfe_handle h) {
   DeviceGuard guard(h->cfg.device);
   if (h->d_dft) (void)hipFree(h->d_dft);
   if (h->d_mel) (void)hipFree(h->d_mel);
-  if (h->d_tickets) (void)hipFree(h->d_tickets);
   if (h->d_resolved) (void)hipFree(h->d_resolved);
   if (h->d_noise_meansq) (void)hipFree(h->d_noise_meansq);
   if (h->d_tile_stats) (void)hipFree(h->d_tile_stats);

@@ -36,7 +36,6 @@ struct FrontArgs {
   float* out;                    // (B, n_mel, T) log10 mel power, or (B, 201, T) power
   int out_kind;                  // log-mel element type: 0 float32, 1 float16, 2 bfloat16 (out then points to 2-byte elements)
   float* tile_stats;             // (B x 64-frame tiles x kTileStats): log10 mel minima [frame group 4][2], maxima [wave 4]
-  unsigned* cu_tickets;          // (4096) arrival counters per CU, zeroed before the launch (stagger heuristic)
   // augmentation (AUG kernels only)
   const wfe_aug_op* ops;
   const int* op_begin;

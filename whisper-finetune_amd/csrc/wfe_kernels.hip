@@ -37,7 +37,7 @@ namespace wfe {
 // Diagnostic build only (make stamps): s_memtime at the phase boundaries of kernel
 // 1, written to a buffer nothing else reads.  The shipped library executes none.
 #ifdef WFE_STAMPS
-constexpr int kStampRow = 16;   // 0..5 phase boundaries, 6/7 stagger + k-loop waits, 8..11 staging passes of SPEED chains
+constexpr int kStampRow = 16;   // 0..5 phase boundaries, 6 hardware id, 7 k-loop waits, 8..11 staging passes of SPEED chains
 #define WFE_STAMP(i)                                                                   \
   do {                                                                                 \
     if (a.stamps && lane == 0) {                                                       \
@@ -819,7 +819,6 @@ __device__ __forceinline__ void stage_augmented(const Chain& c, float* __restric
 // ------------------------------------------------------------- kernel 1
 template <int NMT, bool POWER, bool AUG, int BANK>
 __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
-  constexpr bool STAGGER = !POWER && !AUG;       // (AUG tiles differ in length by themselves: the sleep cost 1 %)
   // waveform image | twiddle slots, reused as the output tile after the k-loop
   constexpr int kAuxFloats = (16 * NMT * kTileStride > 2 * kDftStepFloats) ? 16 * NMT * kTileStride : 2 * kDftStepFloats;
   __shared__ __attribute__((aligned(16))) float lds[kLdsWaveFloats + kAuxFloats];
@@ -877,41 +876,19 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
     }
   }
 
-  // Stagger (speed only, never correctness).  The two workgroups a CU holds are
-  // dispatched together and, doing identical work, would stage, multiply and
-  // store in lockstep, leaving the matrix pipe idle during both epilogues.  The
-  // second workgroup to ARRIVE on a CU in this launch sleeps about one
-  // non-MFMA phase so that its k-loop runs under its neighbour's staging and
-  // epilogue from then on.  The CU is identified from HW_ID / XCC_ID; a wrong
-  // guess only costs the overlap.
-  // (It costs a global atomic round trip, so interior tiles call it with their
-  // waveform loads already in flight.)
-  auto stagger = [&]() {
-    if (!STAGGER) return;
-    if (tid == 0) {
-      const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID
-      const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);      // HW_REG_XCC_ID[3:0]
-      const unsigned key = ((xcc & 15u) << 8) | ((hw >> 8) & 255u);        // xcc | se, sh, cu
-      lds[0] = __uint_as_float(atomicAdd(a.cu_tickets + key, 1u));
-    }
-    __syncthreads();
-    const unsigned ticket = __float_as_uint(lds[0]);
-    __syncthreads();
+  // (A stagger heuristic lived here in early versions: the second workgroup to arrive on a CU slept
+  // one non-MFMA phase so that the two resident workgroups would not run in lockstep.  It helped
+  // the first ~40 launches after idle; at the sustained clock it costs 0.8-1 % on every workload,
+  // plus a memset and an atomic per workgroup, so it is gone.)
 #ifdef WFE_STAMPS
-    if (a.stamps && lane == 0) {
-      const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-      const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
-      unsigned long long* st = a.stamps + ((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + blockIdx.x) * 4 + wave) * kStampRow;
-      st[6] = ((unsigned long long)xcc << 32) | hw;
-      st[7] = ticket;
-    }
+  if (a.stamps && lane == 0) {                  // which SIMD this wave ran on (tools/phase_breakdown.py)
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);       // HW_REG_XCC_ID[3:0]
+    unsigned long long* st = a.stamps + ((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + blockIdx.x) * 4 + wave) * kStampRow;
+    st[6] = ((unsigned long long)xcc << 32) | hw;
+    st[7] = 0;
+  }
 #endif
-    if (ticket == 1u) {
-      __builtin_amdgcn_s_sleep(127);
-      __builtin_amdgcn_s_sleep(127);
-      __builtin_amdgcn_s_sleep(127);
-    }
-  };
 
   // k-steps 0 and 1 of the twiddle table (8 KB each): in flight while the
   // waveform is staged, then parked in the two LDS slots
@@ -939,7 +916,6 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
     const bool interior16 = inside && src.pcm && src.ch == 1 &&
                             ((reinterpret_cast<uintptr_t>(src.pcm + i_first) & 15u) == 0);
     if (AUG) {
-      stagger();
 #ifdef WFE_STAMPS
       stage_augmented<kAuxFloats>(c, lds, lds + kLdsWaveFloats, p0, n, len, tid,
                                   (a.stamps && lane == 0) ? a.stamps + ((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + blockIdx.x) * 4 + wave) * kStampRow : nullptr);
@@ -958,7 +934,6 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
         const int v8 = tid + 256 * it;
         if (v8 < kVec) buf[it] = src8[v8];
       }
-      stagger();
       constexpr float kScale = 1.0f / 32768.0f;
 #pragma unroll
       for (int it = 0; it < kIters; ++it) {
@@ -984,7 +959,6 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
         const int v4 = tid + 256 * it;
         if (v4 < kBlockSamples / 4) buf[it] = src[v4];
       }
-      stagger();
 #pragma unroll
       for (int it = 0; it < kIters; ++it) {
         const int v4 = tid + 256 * it;
@@ -998,7 +972,6 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
         }
       }
     } else {
-      stagger();
       // boundary tiles (reflection, end of the utterance): 41 positions per thread in 2 batches,
       // gathered branch-free (Source::gather) so that a batch is one HBM round trip
       constexpr int kBatch = 21;
