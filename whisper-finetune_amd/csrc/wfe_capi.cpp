@@ -21,6 +21,8 @@ struct wfe_context {
   float* d_dft = nullptr;
   float* d_mel = nullptr;
   wfe::Resolved* d_resolved = nullptr;  // grows on demand
+  void* d_cops = nullptr;               // compiled ops, same capacity as d_resolved
+  wfe::ChainHead* d_heads = nullptr;    // per utterance of a launch slice
   size_t resolved_cap = 0;
   double* d_noise_meansq = nullptr;     // grows on demand
   size_t noise_cap = 0;
@@ -137,10 +139,14 @@ int ensure_aug_workspace(wfe_context* h, size_t total_ops, const float* noise, c
     h->resolved_cap = 0;
     size_t cap = total_ops < 1024 ? 1024 : total_ops * 2;
     HIP_TRY(h, hipMalloc(&h->d_resolved, cap * sizeof(wfe::Resolved)));
+    if (h->d_cops) HIP_TRY(h, hipFree(h->d_cops));
+    h->d_cops = nullptr;
+    HIP_TRY(h, hipMalloc(&h->d_cops, cap * wfe::kCopBytes));
     h->resolved_cap = cap;
   }
   if (!h->d_partials)
     HIP_TRY(h, hipMalloc(&h->d_partials, sizeof(double) * 2 * wfe::kResolveParts * kMaxBatchPerLaunch));
+  if (!h->d_heads) HIP_TRY(h, hipMalloc(&h->d_heads, sizeof(wfe::ChainHead) * kMaxBatchPerLaunch));
   if (n_noise > 0) {
     if ((size_t)n_noise > h->noise_cap) {
       if (h->d_noise_meansq) HIP_TRY(h, hipFree(h->d_noise_meansq));
@@ -209,6 +215,8 @@ int run_frontend(wfe_context* h, const void* wav, int channels, const int64_t* o
       a.noise_off = reinterpret_cast<const long long*>(noise_off);
       a.noise_meansq = h->d_noise_meansq;
       a.resolved = h->d_resolved;
+      a.cops = h->d_cops;
+      a.heads = h->d_heads;
       HIP_TRY(h, wfe::launch_resolve(a, s.count, h->d_partials, stream));
     }
     hipEvent_t* ev = nullptr;
@@ -294,6 +302,8 @@ int wfe_destroy(wfe_handle h) {
   if (h->d_dft) (void)hipFree(h->d_dft);
   if (h->d_mel) (void)hipFree(h->d_mel);
   if (h->d_resolved) (void)hipFree(h->d_resolved);
+  if (h->d_cops) (void)hipFree(h->d_cops);
+  if (h->d_heads) (void)hipFree(h->d_heads);
   if (h->d_noise_meansq) (void)hipFree(h->d_noise_meansq);
   if (h->d_tile_stats) (void)hipFree(h->d_tile_stats);
   for (auto& kv : h->rs_tables)
@@ -413,6 +423,8 @@ int wfe_augment_waveform(wfe_handle h, const float* wav, const int64_t* offsets,
     a.noise_off = reinterpret_cast<const long long*>(noise_offsets);
     a.noise_meansq = h->d_noise_meansq;
     a.resolved = h->d_resolved;
+      a.cops = h->d_cops;
+      a.heads = h->d_heads;
     HIP_TRY(h, wfe::launch_resolve(a, s.count, h->d_partials, stream));
     HIP_TRY(h, wfe::launch_waveform(a, s.count, out + (long long)s.begin * n_samples,
                                     out_lengths ? out_lengths + s.begin : nullptr, stream));

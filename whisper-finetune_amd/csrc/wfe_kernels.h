@@ -17,6 +17,15 @@ struct Resolved {
 
 constexpr int kTileStats = 12;   // floats kernel 1 leaves per 64-frame tile for kernel 2
 
+// What resolve_kernel leaves per utterance for kernel 1: the chain's geometry, and (in `cops`)
+// its ops compiled with their resolved scalars -- kernel 1 then needs two load round trips to
+// set a chain up instead of walking the op list (five dependent ones).
+struct ChainHead {
+  int n_ops, speed_at, len1, compiled;   // compiled: cops hold the chain (n_ops <= 16)
+  double step;
+};
+constexpr int kCopBytes = 48;            // sizeof(COp), wfe_kernels.hip
+
 struct FrontArgs {
   // input
   const float* wav;              // float32 samples, or
@@ -43,6 +52,8 @@ struct FrontArgs {
   const long long* noise_off;
   const double* noise_meansq;    // (n_noise x kNoiseParts) partial sums of squares of each noise clip
   Resolved* resolved;            // (total ops) filled by the reduce kernel
+  void* cops;                    // (total ops x kCopBytes) compiled ops, written by resolve_kernel
+  ChainHead* heads;              // (batch) written by resolve_kernel
   unsigned long long* stamps;    // diagnostic builds (-DWFE_STAMPS) only: 16 clock stamps per wave
 };
 

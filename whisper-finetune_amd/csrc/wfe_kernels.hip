@@ -229,6 +229,7 @@ struct COp {
   double inv;                    // NOISE: 1 / ln
 };
 constexpr int kMaxCops = 16;     // longer chains are evaluated from global memory (slow, correct)
+static_assert(sizeof(COp) == kCopBytes, "wfe_kernels.h: kCopBytes");
 
 struct Chain {
   const COp* cops;               // LDS copy of the ops, or null
@@ -368,6 +369,27 @@ __device__ inline bool compile_chain(const Chain& c, COp* cops, int n_use, int t
   if (n_use > kMaxCops) return false;
   if (tid < n_use) cops[tid] = make_cop(c, tid);
   return true;
+}
+// Kernel 1's set-up: the chain as resolve_kernel compiled it (head + ops -> LDS).  Two load
+// round trips (head / offsets, then the ops); the caller synchronises the workgroup.
+__device__ __forceinline__ Chain load_chain(const FrontArgs& a, int b, const Source& src, int raw_len, COp* cops_lds,
+                                            int tid) {
+  const ChainHead h = a.heads[b];
+  const int lo = a.op_begin[b];
+  Chain c;
+  c.ops = a.ops + lo;
+  c.res = a.resolved + lo;
+  c.n_ops = h.n_ops;
+  c.src = src;
+  c.len0 = raw_len;
+  c.len1 = h.speed_at >= 0 ? h.len1 : raw_len;
+  c.speed_at = h.speed_at;
+  c.step = h.step;
+  c.noise = a.noise;
+  c.noise_off = a.noise_off;
+  c.cops = h.compiled ? cops_lds : nullptr;
+  if (h.compiled && tid < h.n_ops) cops_lds[tid] = reinterpret_cast<const COp*>(a.cops)[lo + tid];
+  return c;
 }
 // (seg_shift_sum / seg_apply below require the compiled chain, c.cops != null)
 __device__ __forceinline__ COp get_cop(const Chain& c, int k) { return c.cops[k]; }
@@ -839,11 +861,9 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   int len = raw_len;
   __shared__ COp cops[AUG ? kMaxCops : 1];
   if (AUG) {
-    c = make_chain(a, b, src, raw_len);
+    c = load_chain(a, b, src, raw_len, cops, tid);
     len = chain_len(c, c.n_ops);
-    const bool compiled = compile_chain(c, cops, c.n_ops, tid);
     __syncthreads();
-    if (compiled) c.cops = cops;
   }
   if (len > n) len = n;                         // truncation=True (HF:300-307)
   const int p0 = t0 * kHop;
@@ -1561,6 +1581,19 @@ __global__ __launch_bounds__(256) void resolve_kernel(const FrontArgs a, const d
     __threadfence();
     __syncthreads();
   }
+  // the chain, compiled with its resolved scalars, for kernel 1 (load_chain)
+  const bool fits = c.n_ops <= kMaxCops;
+  if (fits && (int)threadIdx.x < c.n_ops)
+    reinterpret_cast<COp*>(a.cops)[a.op_begin[b] + threadIdx.x] = make_cop(c, (int)threadIdx.x);
+  if (threadIdx.x == 0) {
+    ChainHead h;
+    h.n_ops = c.n_ops;
+    h.speed_at = c.speed_at;
+    h.len1 = c.len1;
+    h.compiled = fits ? 1 : 0;
+    h.step = c.step;
+    a.heads[b] = h;
+  }
 }
 
 // The augmented waveform itself (stage-level parity tests).  It runs kernel 1's own
@@ -1575,13 +1608,9 @@ __global__ __launch_bounds__(256) void waveform_kernel(const FrontArgs a, float*
   const Source src = make_source(a, b);
   int raw_len = a.lengths[b];
   if (raw_len < 0) raw_len = 0;
-  Chain c = make_chain(a, b, src, raw_len);
   __shared__ COp cops[kMaxCops];
-  {
-    const bool compiled = compile_chain(c, cops, c.n_ops, (int)threadIdx.x);
-    __syncthreads();
-    if (compiled) c.cops = cops;
-  }
+  Chain c = load_chain(a, b, src, raw_len, cops, (int)threadIdx.x);
+  __syncthreads();
   const int L = chain_len(c, c.n_ops);
   const int keep = L < a.n_samples ? L : a.n_samples;
   if (blockIdx.x == 0 && threadIdx.x == 0 && out_len) out_len[b] = L;
