@@ -727,9 +727,7 @@ __device__ __forceinline__ void stage_shipped(const Chain& c, const Shipped f, f
 }
 
 // Stages the augmented padded signal of one workgroup into the LDS image.
-// aux: AUXF floats of LDS free during staging (the seg0 buffer of SPEED chains).
-template <int AUXF>
-__device__ __forceinline__ void stage_augmented(const Chain& c, float* __restrict__ lds, float* __restrict__ aux, int p0, int n,
+__device__ __forceinline__ void stage_augmented(const Chain& c, float* __restrict__ lds, int p0, int n,
                                        int len, int tid, unsigned long long* st = nullptr) {
   Ticker tk;
   tk.start();
@@ -937,10 +935,10 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
                             ((reinterpret_cast<uintptr_t>(src.pcm + i_first) & 15u) == 0);
     if (AUG) {
 #ifdef WFE_STAMPS
-      stage_augmented<kAuxFloats>(c, lds, lds + kLdsWaveFloats, p0, n, len, tid,
+      stage_augmented(c, lds, p0, n, len, tid,
                                   (a.stamps && lane == 0) ? a.stamps + ((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + blockIdx.x) * 4 + wave) * kStampRow : nullptr);
 #else
-      stage_augmented<kAuxFloats>(c, lds, lds + kLdsWaveFloats, p0, n, len, tid);
+      stage_augmented(c, lds, p0, n, len, tid);
 #endif
     } else if (interior16) {
       // 16-bit PCM: 8 samples per 16-byte load, converted on the way into LDS
@@ -1601,9 +1599,8 @@ __global__ __launch_bounds__(256) void resolve_kernel(const FrontArgs a, const d
 // LDS image out, so the bit-exact waveform tests exercise the production evaluator.
 __global__ __launch_bounds__(256) void waveform_kernel(const FrontArgs a, float* __restrict__ out,
                                                        int* __restrict__ out_len) {
-  constexpr int kAux = 2 * kDftStepFloats;
   constexpr int kSpan = kBlockFrames * kHop;            // output samples per workgroup (10240)
-  __shared__ __attribute__((aligned(16))) float lds[kLdsWaveFloats + kAux];
+  __shared__ __attribute__((aligned(16))) float lds[kLdsWaveFloats];
   const int b = blockIdx.y;
   const Source src = make_source(a, b);
   int raw_len = a.lengths[b];
@@ -1615,7 +1612,7 @@ __global__ __launch_bounds__(256) void waveform_kernel(const FrontArgs a, float*
   const int keep = L < a.n_samples ? L : a.n_samples;
   if (blockIdx.x == 0 && threadIdx.x == 0 && out_len) out_len[b] = L;
   const int p0 = blockIdx.x * kSpan;                    // staging position q holds sample p0 + q - 200
-  stage_augmented<kAux>(c, lds, lds + kLdsWaveFloats, p0, a.n_samples, keep, threadIdx.x);
+  stage_augmented(c, lds, p0, a.n_samples, keep, threadIdx.x);
   __syncthreads();
   float* o = out + (long long)b * a.n_samples;
   for (int q = kHalf + threadIdx.x; q < kHalf + kSpan; q += 256) {
