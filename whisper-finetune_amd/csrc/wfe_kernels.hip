@@ -12,8 +12,8 @@
 // K = 100 in 25 k-steps.  B operands (e = x[n]+x[400-n], o = x[n]-x[400-n]) are
 // built from two ds_read_b32 of the LDS tile; A operands (Hann-windowed twiddles,
 // fp64-built, L2 resident, 200 KB): the 8 KB of one k-step are shared by the 4
-// waves through a double-buffered LDS slot (global -> registers two steps ahead,
-// registers -> LDS one step ahead, ds_read_b128 + b96 into ping-pong fragment
+// waves through a double-buffered LDS slot (global -> registers four steps ahead,
+// registers -> LDS two steps ahead, ds_read_b128 + b96 into ping-pong fragment
 // registers one step ahead), one barrier per k-step.  The butterflies
 // Ce+-Co / Se+-So and |.|^2 run on the accumulators, whose C/D layout (frame on
 // the lane, bins in registers) is exactly the B layout the mel MFMA wants, so the
@@ -21,9 +21,15 @@
 // plain stores into the tile's statistics; the block's (n_mel x 64)
 // output tile is transposed through LDS and leaves as 256-byte row segments.
 //
-// Kernel 2 (clamp_kernel): kernel 1 stores (x + 4) / 4 and each workgroup's minimum;
-// kernel 2 applies max(., g(clipmax - 8)) only to the tiles whose minimum is below
-// clipmax - 8 (bit-identical to clamping first: the map is monotone).
+// Kernel 2 (clamp_kernel): kernel 1 stores g(x) = (x + 4) / 4 and, per tile, its minima and
+// per-wave maxima; kernel 2 reduces the utterance maximum from those and applies
+// max(., g(max - 8)) only to the half tiles whose minimum is below max - 8
+// (bit-identical to clamping first: g is monotone -- and so is the rounding of the optional
+// float16 / bfloat16 output).
+//
+// Augmentation (AUG builds): see stage_shipped / seg_apply; data-dependent gains are
+// resolved beforehand by resolve_partial_kernel + resolve_kernel, which also leaves the
+// chain compiled for kernel 1 (load_chain).
 //
 // Numerics: f32 MFMA is a k-ordered fmaf chain (exact f32).  Tables are built in
 // float64 and rounded once.
