@@ -55,6 +55,13 @@ namespace {
 constexpr int kMaxBatchPerLaunch = 4096;
 thread_local std::string g_create_err;
 
+// workspace sizes that wfe_create provides up front, so that the hot path of ordinary batches
+// never reaches hipFree / hipMalloc (larger requests still grow on demand)
+constexpr size_t kInitTiles = (size_t)kMaxBatchPerLaunch * 47;     // 4096 utterances of 30 s
+constexpr size_t kInitOps = (size_t)kMaxBatchPerLaunch * 4;
+constexpr size_t kInitNoise = 1024;
+constexpr size_t kMaxTimedLaunches = 1 << 16;    // event triples kept while wfe_kernel_timing is on
+
 int fail(wfe_context* h, int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
@@ -174,6 +181,7 @@ int run_frontend(wfe_context* h, const void* wav, int channels, const int64_t* o
   const bool aug = ops != nullptr;
   if (aug && !op_begin) return fail(h, WFE_ERR_ARG, "ops given without op_begin");
   if (aug && n_noise > 0 && (!noise || !noise_off)) return fail(h, WFE_ERR_ARG, "n_noise > 0 without a noise bank");
+  if (aug && (total_ops < 0 || n_noise < 0)) return fail(h, WFE_ERR_ARG, "negative total_ops / n_noise");
   if (offsets == nullptr && row_stride < 0) return fail(h, WFE_ERR_ARG, "negative row_stride");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   DeviceGuard guard(h->cfg.device);
@@ -220,7 +228,7 @@ int run_frontend(wfe_context* h, const void* wav, int channels, const int64_t* o
       HIP_TRY(h, wfe::launch_resolve(a, s.count, h->d_partials, stream));
     }
     hipEvent_t* ev = nullptr;
-    if (h->timing) {
+    if (h->timing && h->ev_used / 3 < kMaxTimedLaunches) {   // (beyond the cap launches go untimed)
       if (h->ev_used + 3 > h->ev_pool.size()) {
         for (int i = 0; i < 3; ++i) {
           hipEvent_t e;
@@ -287,6 +295,18 @@ int wfe_create(const wfe_config* cfg, wfe_handle* out) {
   if (e == hipSuccess) e = hipMalloc(&h->d_mel, mel.size() * sizeof(float));
   if (e == hipSuccess) e = hipMemcpy(h->d_dft, dft.data(), dft.size() * sizeof(float), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(h->d_mel, mel.data(), mel.size() * sizeof(float), hipMemcpyHostToDevice);
+  // every workspace of the hot path at the size of an ordinary batch (<= 4096 utterances of 30 s,
+  // <= 4 ops each, <= 1024 noise clips): ~11 MB; only larger requests ever reallocate
+  if (e == hipSuccess) e = hipMalloc(&h->d_tile_stats, kInitTiles * wfe::kTileStats * sizeof(float));
+  if (e == hipSuccess) h->tile_stats_cap = kInitTiles * wfe::kTileStats;
+  if (e == hipSuccess) e = hipMalloc(&h->d_resolved, kInitOps * sizeof(wfe::Resolved));
+  if (e == hipSuccess) e = hipMalloc(&h->d_cops, kInitOps * wfe::kCopBytes);
+  if (e == hipSuccess) h->resolved_cap = kInitOps;
+  if (e == hipSuccess) e = hipMalloc(&h->d_partials, sizeof(double) * 2 * wfe::kResolveParts * kMaxBatchPerLaunch);
+  if (e == hipSuccess) e = hipMalloc(&h->d_heads, sizeof(wfe::ChainHead) * kMaxBatchPerLaunch);
+  if (e == hipSuccess) e = hipMalloc(&h->d_noise_meansq, kInitNoise * wfe::kNoiseParts * sizeof(double));
+  if (e == hipSuccess) h->noise_cap = kInitNoise;
+  if (e == hipSuccess) e = hipMalloc(&h->d_peaks, sizeof(unsigned) * 2 * kMaxBatchPerLaunch);
   if (e != hipSuccess) {
     fail(nullptr, WFE_ERR_HIP, "wfe_create: %s", hipGetErrorString(e));
     wfe_destroy(h);
@@ -407,6 +427,7 @@ int wfe_augment_waveform(wfe_handle h, const float* wav, const int64_t* offsets,
   if (batch == 0) return WFE_OK;
   if (!wav || !lengths || !out || !ops || !op_begin) return fail(h, WFE_ERR_ARG, "null device pointer");
   if (n_noise > 0 && (!noise || !noise_offsets)) return fail(h, WFE_ERR_ARG, "n_noise > 0 without a noise bank");
+  if (total_ops < 0 || n_noise < 0) return fail(h, WFE_ERR_ARG, "negative total_ops / n_noise");
   hipStream_t stream = static_cast<hipStream_t>(stream_);
   DeviceGuard guard(h->cfg.device);
   if (!guard.ok) return fail(h, WFE_ERR_HIP, "hipSetDevice(%d) failed", h->cfg.device);

@@ -295,9 +295,12 @@ __device__ inline float seg_eval(const Chain& c, int lo, int hi, int L, int idx,
         const Resolved r = c.res[k];
         const long long o0 = c.noise_off[op.i0];
         const int ln = (int)(c.noise_off[op.i0 + 1] - o0);
-        const int j = (ln < L) ? (cur % ln) : (cur + op.i1);     // np.pad 'wrap' | slice at start
-        // three separate float32 passes in the reference: no contraction
-        v = add_rn(mul_rn(v, r.a), mul_rn(c.noise[o0 + j], r.b));
+        if (ln > 0) {                                            // (an empty clip mixes nothing in, as noise_gather)
+          int j = (ln < L) ? (cur % ln) : (cur + op.i1);         // np.pad 'wrap' | slice at start
+          j = min(max(j, 0), ln - 1);                            // a start beyond the clip cannot leave it
+          // three separate float32 passes in the reference: no contraction
+          v = add_rn(mul_rn(v, r.a), mul_rn(c.noise[o0 + j], r.b));
+        }
       }
     } else if (op.kind == WFE_AUG_AFFINE) {
       if (in) v = div_rn(sub_rn(v, c.res[k].a), c.res[k].b);

@@ -43,9 +43,14 @@ except Exception:                       # noqa: BLE001
     _sf = None
 
 
-# decoded noise clips of the dataset that was built on a processor: the collator is
-# constructed from the processor alone (finetune.py:70) and finds them here
-_NOISE_CLIPS: dict = {}
+class ClipSet:
+    """Decoded noise clips and impulse responses of ONE dataset with their native rates.
+    The collator is constructed from the processor alone (finetune.py:70), so every item
+    whose plan indexes these clips carries a reference to its dataset's set (``aug_bank``):
+    the indices of a plan can never meet another dataset's clips."""
+
+    def __init__(self, noise=(), noise_rates=None, rir=(), rir_rates=None):
+        self.clips = {"noise": (list(noise), noise_rates), "rir": (list(rir), rir_rates)}
 
 
 # ------------------------------------------------------------------ audio decode
@@ -295,9 +300,13 @@ class CustomDataset(torch.utils.data.Dataset):
                 self.rir_rates.append(int(sr))
             self.planner = AugmentPlanner(self.augment_configs, [len(c) for c in self.noise_clips],
                                           len(self.rir_files or []), noise_rates=self.noise_rates)
-            if self.noise_clips or self.rir_clips:
-                _NOISE_CLIPS[id(processor)] = {"noise": (self.noise_clips, self.noise_rates),
-                                               "rir": (self.rir_clips, self.rir_rates)}
+            # The GPU chain holds one SPEED op per utterance (include/wfe.h wfe_aug_op); the reference
+            # would apply every speed entry of its config (reader.py:248-254).  A config with two of
+            # them is refused here, once and loudly, instead of failing per sample.
+            if sum(1 for cfg in self.augment_configs if cfg.get("type") == "speed") > 1:
+                raise NotImplementedError("augmentation config with more than one 'speed' entry: the GPU chain "
+                                          "supports one speed change per utterance")
+        self.clip_set = ClipSet(self.noise_clips, self.noise_rates, self.rir_clips, self.rir_rates)
 
     @staticmethod
     def _load_wav_files(data_dir):
@@ -394,6 +403,8 @@ class CustomDataset(torch.utils.data.Dataset):
             # "sample_rate": the file's own rate; the collator resamples on the GPU (reader.py:157-158)
             item = {"waveform": sample, "aug_ops": ops, "labels": labels, "id": audio_id, "specaug": False,
                     "sample_rate": sr, "target_rate": self.sample_rate}
+            if ops:
+                item["aug_bank"] = self.clip_set                 # the clips this plan's indices refer to
             if self.augment_configs and self.spec_aug:
                 if random.random() < self.spec_aug.get("prob"):
                     item["specaug"] = self._draw_spec_augmentation()
@@ -493,25 +504,37 @@ class DataCollatorSpeechSeq2SeqWithPadding:
                 raise ValueError(f"WFE_OUTPUT_DTYPE / output_dtype {output_dtype!r} is not float32, float16 or bfloat16")
             output_dtype = getattr(torch, output_dtype)
         self.output_dtype = output_dtype
-        self._clip_src = {"noise": (noise_clips, noise_rates)} if noise_clips is not None else None
+        self._clip_src = ClipSet(noise_clips, noise_rates) if noise_clips is not None else None
         self._noise_banks: dict = {}
         self._packer = None
+        self._fe16 = None                 # own front-end handle for a 16-bit output dtype
 
     def set_noise_clips(self, clips, rates=None, rir_clips=None, rir_rates=None):
         """The decoded noise clips (and impulse responses) of ``CustomDataset`` with their
         native rates (uploaded once; resampled on the GPU per utterance rate on first use)."""
-        self._clip_src = {"noise": (clips, rates), "rir": (rir_clips or [], rir_rates)}
+        self._clip_src = ClipSet(clips, rates, rir_clips or [], rir_rates)
         self._noise_banks = {}
 
-    def _bank(self, fe, rate: int, kind: str = "noise"):
+    def _clip_set_of(self, items) -> Optional[ClipSet]:
+        """The clip set the plans of ``items`` index: the one given to the collator, else the
+        one the items carry (all items of a batch come from one dataset)."""
+        if self._clip_src is not None:
+            return self._clip_src
+        sets = {id(it["aug_bank"]): it["aug_bank"] for it in items if it.get("aug_bank") is not None}
+        if len(sets) > 1:
+            raise ValueError("one batch mixes items of datasets with different noise / reverb clip sets")
+        return next(iter(sets.values())) if sets else None
+
+    def _bank(self, fe, rate: int, kind: str = "noise", clip_set: Optional[ClipSet] = None):
         """Noise clips / impulse responses at ``rate``: what ``librosa.load(path, sr=rate)``
-        hands add_noise / add_reverb (reader.py:323,343), resident on the device."""
+        hands add_noise / add_reverb (reader.py:323,343), resident on the device.  Cached per
+        clip set (the cache entry keeps the set alive, so its id cannot be reused)."""
         from .frontend import NoiseBank
         rate = int(rate)
-        if (kind, rate) in self._noise_banks:
-            return self._noise_banks[(kind, rate)]
-        srcs = self._clip_src if self._clip_src is not None else _NOISE_CLIPS.get(id(self.processor))
-        src = (srcs or {}).get(kind)
+        key = (id(clip_set), kind, rate)
+        if key in self._noise_banks:
+            return self._noise_banks[key][1]
+        src = clip_set.clips.get(kind) if clip_set is not None else None
         bank = None
         if src and src[0]:
             clips, rates = src
@@ -527,10 +550,24 @@ class DataCollatorSpeechSeq2SeqWithPadding:
                         t = o[0, :fe.resampled_length(len(c), int(r), rate)]
                     on_dev.append(t)
                 bank = NoiseBank.from_tensors(on_dev, fe.device)
-        self._noise_banks[(kind, rate)] = bank
+        self._noise_banks[key] = (clip_set, bank)
         return bank
 
-    def _staged(self, fe, group: List[dict], stages: List[list], n_samples: int) -> torch.Tensor:
+    def _bank_for(self, fe, rate: int, plans, clip_set, kind: str = "noise"):
+        """``_bank`` for a launch whose plans may index it: a plan with a NOISE / reverb entry and
+        no clips to index is an error here, on the host -- on the device it would be a read
+        through a null pointer."""
+        bank = self._bank(fe, rate, kind, clip_set)
+        if bank is None:
+            from ._lib import AUG_NOISE
+            needs = kind == "rir" or any(op[0] == AUG_NOISE for plan in plans for op in plan)
+            if needs:
+                raise ValueError(f"an augmentation plan refers to {kind} clips, but the collator has none: the "
+                                 "items must come from the CustomDataset that drew the plans (or pass "
+                                 "noise_clips= / set_noise_clips to the collator)")
+        return bank
+
+    def _staged(self, fe, group: List[dict], stages: List[list], n_samples: int, clip_set=None) -> torch.Tensor:
         """Utterances whose chain spans more than one sampling rate (a file that is not
         at the target rate, or a resample augmentation): every stage but the last is
         [fused chain -> waveform] -> GPU resampler, the last is the fused
@@ -544,35 +581,39 @@ class DataCollatorSpeechSeq2SeqWithPadding:
             host_lens = [st[k]["len_out"] for st in stages]
             if any(plans):
                 width = (max(max(host_lens), 1) + 3) // 4 * 4
-                wav, lens = fe.augment_waveform(wav, lens, plans, self._bank(fe, sr), n_samples=width, offsets=off)
+                wav, lens = fe.augment_waveform(wav, lens, plans, self._bank_for(fe, sr, plans, clip_set),
+                                                n_samples=width, offsets=off)
                 off, ch = None, 1
             if post[0] == "resample":
                 wav, lens = fe.resample(wav, lens, sr, post[1], offsets=off, channels=ch, host_lengths=host_lens)
             else:                                          # reverb: same rate, same lengths
-                wav = fe.reverb(wav, lens, self._bank(fe, sr, "rir"), [st[k]["post"][1] for st in stages],
-                                offsets=off, host_lengths=host_lens)
+                wav = fe.reverb(wav, lens, self._bank_for(fe, sr, plans, clip_set, "rir"),
+                                [st[k]["post"][1] for st in stages], offsets=off, host_lengths=host_lens)
             off, ch = None, 1
         plans = [st[-1]["ops"] for st in stages]
         if any(plans):
-            return fe.augment_logmel(wav, lens, plans, self._bank(fe, stages[0][-1]["sr"]), n_samples=n_samples,
-                                     offsets=off, channels=ch)
+            return fe.augment_logmel(wav, lens, plans, self._bank_for(fe, stages[0][-1]["sr"], plans, clip_set),
+                                     n_samples=n_samples, offsets=off, channels=ch)
         return fe.logmel(wav, lens, n_samples=n_samples, offsets=off, channels=ch)
 
-    def _features(self, items):
-        if self.output_dtype == torch.float32:
-            return self._features_impl(items, None)
+    def _front_end(self, n_mel):
+        """float32: the front end shared with the feature extractor.  A 16-bit output dtype is a
+        setting of the HANDLE, so such a collator owns one of its own instead of toggling the
+        shared one (which other callers may be using)."""
         from .feature_extractor import front_end
-        fe = front_end(self.processor.feature_extractor.feature_size, self.device) \
-            if any("waveform" in it for it in items) else None
-        if fe is not None:
-            fe.set_output_dtype(self.output_dtype)       # the front end is shared with the feature extractor:
-        try:                                             # float32 again when this batch is done
-            return self._features_impl(items, fe).to(self.output_dtype)
-        finally:
-            if fe is not None:
-                fe.set_output_dtype(torch.float32)
+        if self.output_dtype == torch.float32:
+            return front_end(n_mel, self.device)
+        if self._fe16 is None or self._fe16.n_mel != n_mel:
+            from .frontend import HipFrontEnd
+            shared = front_end(n_mel, self.device)                     # (resolves the device the same way)
+            self._fe16 = HipFrontEnd(n_mel=n_mel, device=shared.device)
+            self._fe16.set_output_dtype(self.output_dtype)
+        return self._fe16
 
-    def _features_impl(self, items, _fe):
+    def _features(self, items):
+        return self._features_impl(items).to(self.output_dtype)
+
+    def _features_impl(self, items):
         fe_cfg = self.processor.feature_extractor
         n_mel, n_samples = fe_cfg.feature_size, fe_cfg.n_samples
         frames = n_samples // fe_cfg.hop_length
@@ -583,9 +624,9 @@ class DataCollatorSpeechSeq2SeqWithPadding:
                 raise RuntimeError("the GPU collator must run in the rank's main process: a forked DataLoader "
                                    "worker cannot use the GPU -- launch with --num_workers 0 (host decode is "
                                    "parallelised inside CustomDataset.__getitems__)")
-            from .feature_extractor import front_end
             from .frontend import RaggedPacker
-            fe = front_end(n_mel, self.device)
+            fe = self._front_end(n_mel)
+            clip_set = self._clip_set_of(items)
             if self._packer is None or self._packer.device != fe.device:
                 self._packer = RaggedPacker(fe.device, int(os.environ.get("WFE_DECODE_THREADS", "8")))
             target = int(fe_cfg.sampling_rate)
@@ -606,8 +647,8 @@ class DataCollatorSpeechSeq2SeqWithPadding:
                 flat, off, lens, ch = self._packer.pack([it["waveform"] for it in sel])
                 plans = [it.get("aug_ops") or [] for it in sel]
                 if any(plans):
-                    out = fe.augment_logmel(flat, lens, plans, self._bank(fe, target), n_samples=n_samples, offsets=off,
-                                            channels=ch)
+                    out = fe.augment_logmel(flat, lens, plans, self._bank_for(fe, target, plans, clip_set),
+                                            n_samples=n_samples, offsets=off, channels=ch)
                 else:
                     out = fe.logmel(flat, lens, n_samples=n_samples, offsets=off, channels=ch)
             if staged:
@@ -616,7 +657,7 @@ class DataCollatorSpeechSeq2SeqWithPadding:
                     whole[torch.tensor(simple, device=fe.device)] = out
                 for members in staged.values():
                     part = self._staged(fe, [items[gpu_items[j]] for j, _ in members], [st for _, st in members],
-                                        n_samples)
+                                        n_samples, clip_set)
                     whole[torch.tensor([j for j, _ in members], device=fe.device)] = part
                 out = whole
             for j, i in enumerate(gpu_items):             # reader.py:355-389 on the (1, M, T) layout

@@ -229,10 +229,13 @@ class HipFrontEnd:
     _OP_DTYPE = np.dtype([("kind", "<i4"), ("i0", "<i4"), ("i1", "<i4"), ("i2", "<i4"),
                           ("f0", "<f4"), ("f1", "<f4"), ("d0", "<f8")])     # == wfe_aug_op, 32 bytes
 
-    def pack_plans(self, plans: Sequence[Sequence[tuple]]):
+    def pack_plans(self, plans: Sequence[Sequence[tuple]], noise: Optional["NoiseBank"] = None):
         """plans[b] = list of (kind, i0, i1, i2, f0) -> (device op array, device op_begin,
         total): the arguments of wfe_augment_logmel.  The result may be passed to
-        augment_logmel / augment_waveform in place of ``plans``."""
+        augment_logmel / augment_waveform in place of ``plans``; give the bank those calls
+        will use as ``noise`` to have the plans validated against it here."""
+        if noise is not None:
+            self.validate_plans(plans, noise)
         counts = np.fromiter((len(p) for p in plans), dtype=np.int64, count=len(plans))
         total = int(counts.sum())
         arr = np.zeros(max(total, 1), dtype=self._OP_DTYPE)
@@ -247,16 +250,44 @@ class HipFrontEnd:
         np.cumsum(counts, out=begin[1:])
         return (torch.from_numpy(arr.view(np.uint8)).to(self.device), torch.from_numpy(begin).to(self.device), total)
 
-    def _pack_ops(self, plans):
+    @staticmethod
+    def validate_plans(plans, noise: Optional["NoiseBank"]) -> None:
+        """Host-side check of op lists before they go to the device, where nothing can be
+        checked any more (a NOISE op indexes the noise bank through device pointers: a
+        missing bank or an index outside it would be a GPU memory fault, not an error)."""
+        for b, plan in enumerate(plans):
+            n_speed = 0
+            for op in plan:
+                kind = int(op[0])
+                if kind not in (_lib.AUG_SPEED, _lib.AUG_SHIFT, _lib.AUG_VOLUME, _lib.AUG_NOISE, _lib.AUG_AFFINE):
+                    raise ValueError(f"utterance {b}: op kind {kind} is not a device op (wfe_aug_kind)")
+                if kind == _lib.AUG_SPEED:
+                    n_speed += 1
+                    if int(op[1]) < 0 or n_speed > 1:
+                        raise ValueError(f"utterance {b}: a chain holds at most one SPEED op, with a length >= 0")
+                elif kind == _lib.AUG_NOISE:
+                    if noise is None or noise.n == 0:
+                        raise ValueError(f"utterance {b}: NOISE op without a noise bank")
+                    j, start = int(op[1]), int(op[2])
+                    if not 0 <= j < noise.n:
+                        raise ValueError(f"utterance {b}: noise clip index {j} outside the bank of {noise.n}")
+                    if not 0 <= start <= max(noise.lengths[j] - 1, 0):
+                        raise ValueError(f"utterance {b}: noise start {start} outside clip {j} "
+                                         f"({noise.lengths[j]} samples)")
+
+    def _pack_ops(self, plans, noise=None):
+        """Host op lists are validated and packed; a tuple from ``pack_plans`` is taken as it is
+        (it was validated when it was packed IF a bank was given there)."""
         if isinstance(plans, tuple) and len(plans) == 3 and isinstance(plans[0], torch.Tensor):
             return plans
+        self.validate_plans(plans, noise)
         return self.pack_plans(plans)
 
     def augment_logmel(self, wav, lengths, plans, noise: Optional[NoiseBank] = None, n_samples: int = N_SAMPLES,
                        offsets=None, out=None, channels: int = 1) -> torch.Tensor:
         batch, stride = self._geometry(wav, lengths, offsets)
         self._check_inputs(wav, lengths, offsets, batch)
-        ops, begin, total = self._pack_ops(plans)
+        ops, begin, total = self._pack_ops(plans, noise)
         if begin.numel() != batch + 1:
             raise ValueError("one op list per utterance")
         shape = (batch, self.n_mel, n_samples // HOP)
@@ -275,7 +306,7 @@ class HipFrontEnd:
                          offsets=None):
         batch, stride = self._geometry(wav, lengths, offsets)
         self._check_inputs(wav, lengths, offsets, batch)
-        ops, begin, total = self._pack_ops(plans)
+        ops, begin, total = self._pack_ops(plans, noise)
         out = torch.empty((batch, n_samples), dtype=torch.float32, device=self.device)
         out_len = torch.empty((batch,), dtype=torch.int32, device=self.device)
         _lib.check(_lib.lib().wfe_augment_waveform(
