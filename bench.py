@@ -10,10 +10,14 @@ independent, there is no data-path collective -- so scaling is weak
 and `value` is the sum over ranks.
 
 Prints ONE JSON line on rank 0.  Besides the driver's contract it carries
-  roofline      achieved = SURVEY 8d algorithmic FLOPs (1.061 GF per 30 s clip at
-                80 mel) x clips per launch / mean device time of the STFT+mel
-                kernel, measured with HIP events on the launch stream inside the
-                timed region; peak = 157.3 TFLOP/s (f32 MFMA, MI355X_MICROARCH.md)
+  roofline      achieved = the f32 MFMA FLOPs the folded DFT + mel kernel has to issue
+                (0.297 GF per 30 s clip at 80 mel: the fold removes 3/4 of the
+                1.061 GF a plain 400x402 DFT-GEMM is priced at in SURVEY 8d; that
+                figure is reported as priced_tflops) x clips per launch / mean device
+                time of the kernel, measured with HIP events on the launch stream
+                inside the timed region; peak = 157.3 TFLOP/s (f32 MFMA,
+                MI355X_MICROARCH.md); frac = achieved / peak <= 1.  hbm_floor_frac =
+                algorithmic bytes / 8 TB/s / kernel time.
   cpu_baseline  the CPU oracle (a torch.stft restatement of the reference
                 extractor, oracle/logmel.py) timed on this box's host cores on a
                 bounded sample, rank 0 at N=1 only.
@@ -41,6 +45,62 @@ ALGO_GFLOP = {80: 1.0613, 128: 1.1192}       # 2*3000*400*402 + 2*300
 ALGO_BYTES = {80: 2.88e6, 128: 3.456e6}      # waveform read + log-mel write
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_HBM_GBS = 8000.0
+
+
+def executed_gflop_per_clip(n_mel: int) -> float:
+    """The algorithmic work of the FOLDED formulation: 47 tiles x 4 waves x
+    (4 GEMMs x 7 bin tiles x 25 k-steps = 700 DFT + 72 | 84 mel) v_mfma_f32_16x16x4_f32 of
+    2048 FLOP each.  SQ_INSTS_MFMA per launch equals this count exactly (profiles/)."""
+    return 47 * 4 * (700 + (72 if n_mel <= 80 else 84)) * 2048 / 1e9
+
+
+def measured_traffic(batch: int, n_mel: int, augment: bool, lengths: str):
+    """HBM bytes per launch of kernel 1 (and of the clamp kernel) from profiles/traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command line, one entry per
+    (batch, n_mel, augment, lengths).  None when that configuration was not profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            tj = json.load(f)
+        for e in tj["entries"]:
+            if (e["batch"], e["n_mel"], bool(e["augment"]), e.get("lengths", "full")) == (batch, n_mel, augment, lengths):
+                return e
+    except Exception:  # noqa: BLE001
+        pass
+    return None
+
+
+def launch_command(n_gpus: int, argv, port: int):
+    """The command the driver itself uses for N > 1 (one rank per GPU over RCCL); bench.py
+    starts it as a CHILD when asked for --gpus N outside a torchrun launch."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, argv) -> int:
+    """--gpus N > 1 without WORLD_SIZE: start the N ranks (before this process touches a GPU),
+    relay rank 0's JSON line, exit non-zero if any rank fails.  Never retried, never re-exec'd."""
+    import socket
+    import subprocess
+    if not args.stub_transform:
+        n_dev = torch.cuda.device_count()            # counting devices does not initialise the GPU
+        if n_dev < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(launch_command(args.gpus, argv, port), env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    for ln in proc.stdout.splitlines():
+        if not ln.startswith("{"):
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: a rank failed (exit {proc.returncode})")
+    if not lines:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: no JSON line from rank 0")
+    print(lines[-1], flush=True)
+    return 0
 
 
 def device_clips(batch: int, device, seed0: int) -> torch.Tensor:
@@ -100,38 +160,61 @@ def cpu_baseline(n_mel: int, budget_s: float = 15.0) -> dict:
 def shard_workload(args, fe, device, rank, world, dist) -> None:
     """BASELINE config 4: N clips sharded data-parallel, no data-path collective."""
     from wfe_amd.sharded import run_sharded
-    pool = device_clips(2 * args.batch, device, seed0=0)              # clip i -> pool row, a zero-copy view
-    lens = torch.full((args.batch,), N_SAMPLES, dtype=torch.int32, device=device)
-    out = torch.empty((args.batch, args.n_mel, N_SAMPLES // 160), dtype=torch.float32, device=device)
+    frames = N_SAMPLES // 160
+    if args.stub_transform:
+        # plumbing test only (CPU, gloo): no front end, a stand-in transform; never a measurement
+        base = torch.arange(args.batch, dtype=torch.float32).reshape(-1, 1).repeat(1, 320)
+        pool = torch.cat([base, base])
+        lens = torch.full((args.batch,), 320, dtype=torch.int32)
+
+        def transform(wav, ln):
+            return wav[:, :2].reshape(wav.shape[0], 1, 2) + 1.0
+        sync = None
+    else:
+        # clip i = base clip i % batch, whatever the shard or batch start: the pool holds the base
+        # clips twice, so that any batch [begin, begin + count) is a zero-copy view of it
+        base = device_clips(args.batch, device, seed0=0)
+        pool = torch.cat([base, base])
+        del base
+        lens = torch.full((args.batch,), N_SAMPLES, dtype=torch.int32, device=device)
+        fe.set_output_dtype(getattr(torch, args.out_dtype))
+        out = torch.empty((args.batch, args.n_mel, frames), dtype=fe.out_dtype, device=device)
+
+        def transform(wav, ln):
+            return fe.logmel(wav, ln, out=out[:wav.shape[0]])
+        sync = torch.cuda.synchronize
 
     def make_batch(begin, count):
         o = begin % args.batch
         return pool[o:o + count], lens[:count]
 
-    def transform(wav, ln):
-        return fe.logmel(wav, ln, out=out[:wav.shape[0]])
-
-    run_sharded(min(args.shard_clips, 4 * args.batch * world), args.batch, make_batch, transform,
-                sync=torch.cuda.synchronize, checksum_stride=1021)     # warm-up
-    res = run_sharded(args.shard_clips, args.batch, make_batch, transform, sync=torch.cuda.synchronize,
-                      checksum_stride=1021)
+    warm = min(args.shard_clips, 4 * args.batch * world)
+    run_sharded(warm, args.batch, make_batch, transform, sync=sync, checksum_stride=1021)     # warm-up
+    res = run_sharded(args.shard_clips, args.batch, make_batch, transform, sync=sync, checksum_stride=1021)
+    steps = max(1, -(-args.shard_clips // (args.batch * world)))
     if rank == 0:
         print(json.dumps({
             "metric": "log-mel audio-hours/sec", "value": res["items"] * CLIP_HOURS / res["seconds"],
-            "unit": "audio-hours/sec", "n_gpus": world, "steps": -(-args.shard_clips // (args.batch * world)),
-            "warmup": 4, "ms_per_step": res["seconds"] / max(1, -(-args.shard_clips // (args.batch * world))) * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "unit": "audio-hours/sec", "n_gpus": world, "steps": steps,
+            "warmup": max(1, -(-warm // (args.batch * world))), "ms_per_step": res["seconds"] / steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": DTYPE_NAME[args.out_dtype], "data": "stub" if args.stub_transform else "synthetic",
             "config": {"workload": f"whisper-large-v3 {args.n_mel}-mel front end, {args.shard_clips} synthetic 30 s "
-                                   f"clips sharded contiguously over {world} GPU(s), batches of {args.batch}",
+                                   f"clips sharded contiguously over {world} GPU(s), batches of {args.batch}"
+                                   + (" [STUB TRANSFORM: plumbing test, not a measurement]" if args.stub_transform else ""),
                        "parallelism": f"dp{world} (utterances sharded, no data-path collective)"},
-            "clips_per_sec": res["items"] / res["seconds"], "checksum": res["checksum"]}), flush=True)
+            "clips_per_sec": res["items"] / res["seconds"], "items": res["items"], "checksum": res["checksum"]}),
+            flush=True)
     if dist:
         import torch.distributed as td
         td.barrier()
         td.destroy_process_group()
 
 
-def main() -> None:
+DTYPE_NAME = {"float32": "f32", "float16": "f16", "bfloat16": "bf16"}
+
+
+def main(argv=None) -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # the first ~40 launches after an idle period run 10 % slower (clock ramp): the defaults time the
@@ -163,14 +246,33 @@ def main() -> None:
     ap.add_argument("--shard-clips", type=int, default=0,
                     help="BASELINE config 4 instead of the default workload: this many clips in all, contiguous "
                          "shards per rank (wfe_amd.sharded), batches of --batch; use with --n-mel 128")
-    args = ap.parse_args()
+    ap.add_argument("--stub-transform", action="store_true",
+                    help="plumbing test of the multi-rank launch on CPU (gloo) with a stand-in transform; only with "
+                         "--shard-clips; the line it prints says so and is not a measurement")
+    args = ap.parse_args(argv)
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args, sys.argv[1:] if argv is None else argv))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: they must agree")
     dist = world > 1
+    if args.stub_transform:
+        if not args.shard_clips:
+            raise SystemExit("--stub-transform is a plumbing test of --shard-clips only")
+        if dist:
+            import torch.distributed as td
+            td.init_process_group("gloo")
+        shard_workload(args, None, torch.device("cpu"), rank, world, dist)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the front end has no CPU path")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if dist:
@@ -289,19 +391,20 @@ def main() -> None:
     if rank == 0:
         clips = args.batch * args.steps * world
         k1_avg_s = k1_ms / max(launches, 1) / 1e3
-        achieved = ALGO_GFLOP[args.n_mel] * args.batch / k1_avg_s / 1e3          # TFLOP/s
-        traffic, traffic_src, clamp_gbs = None, None, None
-        try:   # HBM bytes per launch measured offline with rocprofv3 PMC passes (same batch / n_mel only)
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-            if tj["batch"] == args.batch and tj["n_mel"] == args.n_mel:
-                traffic = (tj["frontend_kernel"]["fetch_bytes"] + tj["frontend_kernel"]["write_bytes"]) / 1e9
-                if not args.augment and args.lengths == "full" and k2_ms > 0:      # data-dependent: same clips only
-                    ck = tj["clamp_kernel"]
-                    clamp_gbs = (ck["fetch_bytes"] + ck["write_bytes"]) / (k2_ms / max(launches, 1) / 1e3) / 1e9
-                traffic_src = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, GB per launch; " \
-                              "algorithmic %.3f GB)" % (ALGO_BYTES[args.n_mel] * args.batch / 1e9)
-        except Exception:  # noqa: BLE001
-            pass
+        k2_avg_s = k2_ms / max(launches, 1) / 1e3
+        achieved = executed_gflop_per_clip(args.n_mel) * args.batch / k1_avg_s / 1e3     # TFLOP/s the MFMA pipe ran
+        priced = ALGO_GFLOP[args.n_mel] * args.batch / k1_avg_s / 1e3                    # SURVEY 8d, unfolded
+        algo_bytes = ALGO_BYTES[args.n_mel] * args.batch
+        traffic, traffic_src, clamp_gbs, clamp_traffic = None, None, None, None
+        te = measured_traffic(args.batch, args.n_mel, args.augment, args.lengths)
+        if te is not None and not args.pcm16 and args.out_dtype == "float32":
+            traffic = (te["frontend_kernel"]["fetch_bytes"] + te["frontend_kernel"]["write_bytes"]) / 1e9
+            ck = te.get("clamp_kernel")
+            if ck and k2_ms > 0:                                                          # data-dependent: same clips only
+                clamp_traffic = (ck["fetch_bytes"] + ck["write_bytes"]) / 1e9
+                clamp_gbs = clamp_traffic / k2_avg_s
+            traffic_src = "profiles/traffic.json entry %r (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, GB per " \
+                          "launch; algorithmic %.3f GB)" % (te.get("source", "?"), algo_bytes / 1e9)
         line = {
             "metric": "log-mel audio-hours/sec",
             "value": clips * CLIP_HOURS / elapsed,
@@ -313,7 +416,7 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": DTYPE_NAME[args.out_dtype],
             "data": "synthetic",
             "config": {"workload": f"whisper-small {args.n_mel}-mel front end, batch {args.batch} synthetic 30 s "
                                    f"16 kHz clips per GPU, {aug_note}, input resident in HBM"
@@ -325,19 +428,21 @@ def main() -> None:
                        "parallelism": f"dp{world} (utterances sharded, no data-path collective)"},
             "clips_per_sec": clips / elapsed,
             "roofline": {
+                # executed f32 MFMA rate of the folded DFT + mel kernel against the matrix-pipe peak
                 "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "wfe::frontend_kernel", "kernel_ms_avg": k1_avg_s * 1e3, "launches": launches,
-                "algorithmic_gflop_per_clip": ALGO_GFLOP[args.n_mel],
-                # what the folded-DFT kernel actually issues: 47 blocks x 4 waves x (700 DFT + 72|84 mel)
-                # v_mfma_f32_16x16x4_f32 of 2048 FLOP each
-                "executed_mfma_gflop_per_clip": 47 * 4 * (700 + (72 if args.n_mel <= 80 else 84)) * 2048 / 1e9,
-                "executed_mfma_tflops": 47 * 4 * (700 + (72 if args.n_mel <= 80 else 84)) * 2048 * args.batch
-                / k1_avg_s / 1e12,
-                "clamp_kernel_ms_avg": k2_ms / max(launches, 1),
+                "gflop_per_clip": executed_gflop_per_clip(args.n_mel),
+                # the same launch priced with SURVEY 8d's unfolded 400x402 DFT-GEMM (can exceed the peak:
+                # the fold removes 3/4 of those FLOPs) -- not a roofline fraction
+                "priced_gflop_per_clip": ALGO_GFLOP[args.n_mel], "priced_tflops": priced,
+                # against the other roof: algorithmic bytes (waveform read + log-mel write) at 8 TB/s
+                "hbm_algorithmic_gb": algo_bytes / 1e9, "hbm_algorithmic_gbs": algo_bytes / k1_avg_s / 1e9,
+                "hbm_floor_ms": algo_bytes / (PEAK_HBM_GBS * 1e9) * 1e3,
+                "hbm_floor_frac": algo_bytes / (PEAK_HBM_GBS * 1e9) / k1_avg_s,
+                "clamp_kernel_ms_avg": k2_avg_s * 1e3, "clamp_kernel_traffic": clamp_traffic,
                 # the elementwise stage against HBM: measured bytes (profiles/traffic.json) / measured time
                 "clamp_kernel_hbm_gbs": clamp_gbs, "clamp_kernel_hbm_frac": clamp_gbs / PEAK_HBM_GBS if clamp_gbs else None,
-                "hbm_algorithmic_gbs": ALGO_BYTES[args.n_mel] * args.batch / k1_avg_s / 1e9,
             },
             "checksum": checksum,
         }

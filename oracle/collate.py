@@ -10,7 +10,7 @@ from __future__ import annotations
 import numpy as np
 
 
-def collate(items, n_mel, frames, strip_token=None, with_ids=False):
+def collate(items, n_mel, frames, strip_tokens=(), with_ids=False):
     """items: dicts with 'input_features' ((1, M, T) array or None), 'labels', 'id'."""
     kept = [it for it in items if it.get("input_features") is not None]
     feats = np.zeros((len(kept), n_mel, frames), dtype=np.float32)
@@ -20,7 +20,9 @@ def collate(items, n_mel, frames, strip_token=None, with_ids=False):
     labels = np.full((len(kept), width), -100, dtype=np.int64)
     for i, it in enumerate(kept):
         labels[i, :len(it["labels"])] = it["labels"]
-    if strip_token is not None and len(kept) and width and (labels[:, 0] == strip_token).all():
+    # training variant: a start token shared by every row is dropped (the model prepends its
+    # decoder start token when it shifts the labels right); the eval variant keeps the prompt
+    if len(kept) and width and any((labels[:, 0] == t).all() for t in strip_tokens):
         labels = labels[:, 1:]
     out = {"input_features": feats, "labels": labels}
     if with_ids:

@@ -39,6 +39,14 @@ def noise_clip(j: int, seconds: float = 10.0) -> np.ndarray:
     return (0.05 * rng.standard_normal(int(seconds * SR))).astype(np.float32)
 
 
+def rir_clip(seed: int, taps: int) -> np.ndarray:
+    """A synthetic room impulse response: direct path + exponentially decaying noise tail."""
+    rng = np.random.default_rng(7000 + seed)
+    h = rng.standard_normal(taps) * np.exp(-np.arange(taps) / (0.2 * taps + 1.0))
+    h[0] = 1.0
+    return (0.5 * h).astype(np.float32)
+
+
 def load_test_wav() -> np.ndarray:
     """The reference's dataset/test.wav (mono 16 kHz s16, 134240 frames) decoded
     as soundfile.read(dtype='float32') does: int16 / 32768."""

@@ -24,6 +24,8 @@ import sys
 import types
 
 import numpy as np
+from transformers import WhisperFeatureExtractor  # noqa: F401  (before the librosa stand-in exists: its
+                                                  # availability probe rejects a module without a spec)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
@@ -151,6 +153,186 @@ def augment_goldens():
     print("augment goldens:", len(out), "arrays")
 
 
+def _reference_dataset_class():
+    """The reference's CustomDataset, imported with empty stand-in modules for the two
+    packages that are not installed; the few functions of them the executed code reaches
+    are set by the callers below (decode of dataset/test.wav through the stdlib ``wave``
+    module = what soundfile returns for 16-bit PCM; seeded clips for librosa.load)."""
+    for missing in ("librosa", "soundfile"):
+        if missing not in sys.modules:
+            sys.modules[missing] = types.ModuleType(missing)
+    if "/root/reference" not in sys.path:
+        sys.path.insert(0, "/root/reference")
+    from utils.reader import CustomDataset
+    return CustomDataset
+
+
+def reverb_goldens():
+    """CustomDataset.add_reverb (utils/reader.py:342-348) and the whole augment() chain with the
+    reverb entry firing, run by the reference itself; librosa.load returns seeded impulse
+    responses / noise clips (decode is outside the pinned path)."""
+    CustomDataset = _reference_dataset_class()
+    import librosa
+    out = {}
+    rng = np.random.default_rng(4242)
+    base = (0.1 * rng.standard_normal(16000)).astype(np.float32)
+    odd = (0.1 * rng.standard_normal(12347)).astype(np.float32)
+    out["in_base"], out["in_odd"] = base, odd
+    ds = object.__new__(CustomDataset)
+    for tag, taps in (("t64", 64), ("t801", 801), ("t1600", 1600), ("t4000", 4000)):
+        rir = cases.rir_clip(taps, taps)
+        out[f"rir_{tag}"] = rir
+        librosa.load = lambda path, sr, _r=rir: (_r.copy(), sr)
+        for name, x in (("base", base), ("odd", odd)):
+            y = ds.add_reverb(x.copy(), 16000, "rir.wav")
+            assert y.dtype == np.float32 and y.shape == x.shape
+            out[f"reverb_{tag}_{name}"] = y
+    # the chain in shipped file order with noise, reverb, speed, shift, volume all firing
+    with open("/root/reference/configs/augmentation.json") as f:
+        cfg = json.load(f)
+    for c in cfg:
+        if c["type"] in ("speed", "shift", "volume", "noise", "reverb"):
+            c["prob"] = 1.0
+    out["chain_config_json"] = np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8)
+    bank = [cases.noise_clip(j, 0.3 + 0.35 * j) for j in range(4)]
+    rirs = [cases.rir_clip(100 + j, 300 + 250 * j) for j in range(3)]
+    for j, r in enumerate(rirs):
+        out[f"chain_rir_{j}"] = r
+    ds.augment_configs = cfg
+    ds.noise_files = [f"n{j}.wav" for j in range(4)]
+    ds.rir_files = [f"r{j}.wav" for j in range(3)]
+    ds.speed_rates = None
+
+    def load(path, sr):
+        name = os.path.basename(path)
+        return ((bank if name[0] == "n" else rirs)[int(name[1])].copy(), sr)
+    librosa.load = load
+    for s in range(6):
+        random.seed(40 + s)
+        src = (0.1 * np.random.default_rng(700 + s).standard_normal(9000 + 1111 * s)).astype(np.float32)
+        res, sr = ds.augment(src.copy(), 16000)
+        assert sr == 16000 and res.dtype == np.float32
+        out[f"chain_{s}"] = res
+        out[f"chain_{s}_next_random"] = np.asarray(random.random())
+    np.savez_compressed(os.path.join(HERE, "reverb_golden.npz"), **out)
+    print("reverb goldens:", len(out), "arrays")
+
+
+def dataset_goldens():
+    """The reference's CustomDataset end to end on dataset/test.wav: manifests written by the
+    reference's own DatasetWriter (utils/binary.py:9-35), items from its __getitem__
+    (timestamp labels reader.py:164-179, the no-text branch :196-199, slices :222-243) and its
+    spec_augmentation (:355-389) on the real (1, n_mel, 3000) layout.  Tokenizer = tests/stubs.py
+    (no Whisper vocabulary exists offline): the label ARITHMETIC is the reference's."""
+    import wave
+    import stubs
+    CustomDataset = _reference_dataset_class()
+    import librosa
+    import soundfile
+    from utils.binary import DatasetWriter
+
+    wav_rel = "tests/golden/test.wav"                      # manifest paths are relative to the repository root
+    root = os.path.dirname(os.path.dirname(HERE))
+
+    class SoundFile:                                       # the four members slice_from_file uses
+        def __init__(self, path):
+            self._w = wave.open(os.path.join(root, path))
+            self.samplerate = self._w.getframerate()
+        def __len__(self):
+            return self._w.getnframes()
+        def seek(self, frame):
+            self._w.setpos(frame)
+        def read(self, frames, dtype):
+            assert dtype == "float32" and self._w.getsampwidth() == 2 and self._w.getnchannels() == 1
+            return np.frombuffer(self._w.readframes(frames), dtype="<i2").astype(np.float32) / np.float32(32768.0)
+
+    def sf_read(path, dtype):
+        f = SoundFile(path)
+        return f.read(len(f), dtype), f.samplerate
+    soundfile.read, soundfile.SoundFile = sf_read, SoundFile
+    librosa.to_mono = lambda y: y if y.ndim == 1 else np.mean(y, axis=tuple(range(y.ndim - 1)))
+
+    segs = [{"start": 0.0, "end": 1.51, "text": "ab"}, {"start": 1.53, "end": 2.9, "text": "c"},
+            {"start": 3.07, "end": 8.39, "text": "whisper"}]
+    recs = [
+        {"audio": {"path": wav_rel}, "sentence": "hello world", "duration": 8.39, "sentences": segs},
+        {"audio": {"path": wav_rel}, "sentence": "too short", "duration": 0.3, "sentences": segs[:1]},
+        {"audio": {"path": wav_rel, "start_time": 1.2345, "end_time": 4.5678}, "sentence": "a slice", "duration": 3.33,
+         "sentences": segs[:2], "language": "zh", "id": "slice-1"},
+        {"audio": {"path": wav_rel}, "sentence": "", "duration": 8.39, "sentences": []},
+        {"audio": {"path": wav_rel}, "sentence": "too long", "duration": 31.0, "sentences": segs},
+        {"audio": {"path": wav_rel, "start_time": -3.0, "end_time": -0.5}, "sentence": "from the end", "duration": 2.5,
+         "sentences": [{"start": 0.01, "end": 2.49, "text": "z"}]},
+    ]
+    writer = DatasetWriter(os.path.join(HERE, "manifest"))          # -> manifest.data / manifest.header
+    for r in recs:
+        writer.add_data(json.dumps(r))
+    writer.close()
+    with open(os.path.join(HERE, "manifest.jsonl"), "w", encoding="utf-8") as f:
+        f.write("\n".join(json.dumps(r) for r in recs))
+
+    cwd = os.getcwd()
+    os.chdir(root)
+    try:
+        meta, arrays = {}, {}
+        keep = cases.kept_frames(3000)
+        for n_mel in (80, 128):
+            for mode, ts in (("text", False), ("timestamps", True)):
+                for src in ("header", "jsonl"):
+                    ds = CustomDataset(os.path.join("tests/golden", "manifest." + src), stubs.StubProcessor(n_mel),
+                                       timestamps=ts, language="en")
+                    items = []
+                    for i in range(len(ds)):
+                        it = ds[i]
+                        feats = np.asarray(it["input_features"])
+                        assert feats.shape == (1, n_mel, 3000) and feats.dtype == np.float32
+                        items.append({"id": it["id"], "labels": [int(t) for t in it["labels"]]})
+                        if src == "header":
+                            arrays[f"{mode}_{n_mel}_{i}"] = feats[0][:, keep]
+                    meta[f"{mode}_{n_mel}_{src}"] = items
+        # spec_augmentation on the real layout, called directly and through __getitem__
+        for n_mel in (80, 128):
+            ds = CustomDataset("tests/golden/manifest.jsonl", stubs.StubProcessor(n_mel), language="en")
+            feats = np.asarray(ds[0]["input_features"])
+            for s in range(3):
+                random.seed(900 + s)
+                got = ds.spec_augmentation({"input_features": feats.copy()})["input_features"]
+                assert tuple(got.shape) == (1, n_mel, 3000)
+                arrays[f"specaug_direct_{n_mel}_{s}"] = got.numpy()
+                meta[f"specaug_direct_{n_mel}_{s}_next_random"] = random.random()
+        cfgp = os.path.join(HERE, "specaug_config.json")
+        with open(cfgp, "w") as f:
+            json.dump([{"type": "volume", "params": {"min_gain_dBFS": -15, "max_gain_dBFS": 15}, "prob": 0.0},
+                       {"type": "specaug", "params": {"num_t_mask": 2, "num_f_mask": 2, "max_t": 50, "max_f": 10},
+                        "prob": 0.5}], f)
+        ds = CustomDataset("tests/golden/manifest.jsonl", stubs.StubProcessor(80), language="en",
+                           augment_config_path=cfgp)
+        random.seed(77)
+        fired = []
+        for rep in range(8):
+            it = ds[rep % len(ds)]
+            f = it["input_features"]
+            is_tensor = not isinstance(f, np.ndarray)
+            fired.append(bool(is_tensor))
+            arr = f.numpy() if is_tensor else np.asarray(f)
+            arrays[f"specaug_item_{rep}"] = arr[0][:, keep]
+        meta["specaug_item_fired"] = fired
+        meta["specaug_item_next_random"] = random.random()
+    finally:
+        os.chdir(cwd)
+    np.savez_compressed(os.path.join(HERE, "dataset_golden.npz"), **arrays)
+    with open(os.path.join(HERE, "dataset_golden.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    print("dataset goldens:", len(arrays), "arrays,", len(meta), "records")
+
+
 if __name__ == "__main__":
-    logmel_goldens()
-    augment_goldens()
+    which = sys.argv[1:] or ["logmel", "augment", "reverb", "dataset"]
+    if "logmel" in which:
+        logmel_goldens()
+    if "augment" in which:
+        augment_goldens()
+    if "reverb" in which:
+        reverb_goldens()
+    if "dataset" in which:
+        dataset_goldens()

@@ -37,3 +37,20 @@ class StubProcessor:
     def __init__(self, n_mel=80, feature_extractor=None):
         self.tokenizer = StubTokenizer()
         self.feature_extractor = feature_extractor or WhisperFeatureExtractor(feature_size=n_mel)
+
+    def __call__(self, audio=None, sampling_rate=None, text=None):
+        """The routing of WhisperProcessor.__call__ (transformers processing_whisper.py:31-54):
+        audio -> feature extractor, text -> tokenizer, both -> features with ``labels``.  Only the
+        golden generator calls this (the reference's CustomDataset runs the processor per item,
+        reader.py:174,192,195,198); the GPU dataset never does."""
+        from transformers.feature_extraction_utils import BatchFeature
+        if audio is None and text is None:
+            raise ValueError("You need to specify either an `audio` or `text` input to process.")
+        inputs = self.feature_extractor(audio, sampling_rate=sampling_rate) if audio is not None else None
+        enc = BatchFeature({"input_ids": self.tokenizer(text).input_ids}) if text is not None else None
+        if text is None:
+            return inputs
+        if audio is None:
+            return enc
+        inputs["labels"] = enc["input_ids"]
+        return inputs

@@ -467,15 +467,15 @@ class CustomDataset(torch.utils.data.Dataset):
 
 
 # ------------------------------------------------------------------ collators
-def _pad_labels(rows: List[List[int]], strip_token: Optional[int]) -> torch.Tensor:
+def _pad_labels(rows: List[List[int]], strip_tokens=()) -> torch.Tensor:
     width = max((len(r) for r in rows), default=0)
     out = torch.full((len(rows), width), -100, dtype=torch.int64)
     for i, r in enumerate(rows):
         out[i, :len(r)] = torch.as_tensor(r, dtype=torch.int64)
-    # training convention of the upstream project (not verifiable in the reference
-    # tree): drop a leading BOS shared by every row; the model re-adds the decoder
-    # start token by shifting the labels right
-    if strip_token is not None and width > 0 and len(rows) > 0 and bool((out[:, 0] == strip_token).all()):
+    # Training convention (not verifiable in the reference tree): the model builds
+    # decoder_input_ids by shifting the labels right and prepending its decoder start token, so a
+    # start token shared by every row is dropped here -- otherwise the decoder would see it twice.
+    if width > 0 and len(rows) > 0 and any(t is not None and bool((out[:, 0] == t).all()) for t in strip_tokens):
         out = out[:, 1:]
     return out
 
@@ -508,6 +508,23 @@ class DataCollatorSpeechSeq2SeqWithPadding:
         self._noise_banks: dict = {}
         self._packer = None
         self._fe16 = None                 # own front-end handle for a 16-bit output dtype
+
+    def _strip_tokens(self):
+        """Leading label tokens the training collator drops when every row starts with one of them:
+        the tokenizer's ``bos_token_id`` (the check of the upstream project's collator; for Whisper
+        tokenizers that is <|endoftext|>, which never leads a label row) and
+        <|startoftranscript|>, the decoder start token the model prepends itself
+        (WhisperForConditionalGeneration shifts the labels right).  The eval collator keeps
+        the prompt: evaluation.py:106 feeds labels[:, :4] to generate()."""
+        if self.keep_prompt:
+            return ()
+        tok = self.processor.tokenizer
+        sot = None
+        try:
+            sot = tok.get_vocab().get("<|startoftranscript|>")
+        except Exception:  # noqa: BLE001
+            pass
+        return (getattr(tok, "bos_token_id", None), sot)
 
     def set_noise_clips(self, clips, rates=None, rir_clips=None, rir_rates=None):
         """The decoded noise clips (and impulse responses) of ``CustomDataset`` with their
@@ -689,9 +706,8 @@ class DataCollatorSpeechSeq2SeqWithPadding:
             if self.with_ids:
                 batch["id"] = []
             return batch
-        strip = None if self.keep_prompt else getattr(self.processor.tokenizer, "bos_token_id", None)
         batch = {"input_features": self._features(items),
-                 "labels": _pad_labels([list(f["labels"]) for f in items], strip)}
+                 "labels": _pad_labels([list(f["labels"]) for f in items], self._strip_tokens())}
         if self.with_ids:
             batch["id"] = [f["id"] for f in items]
         return batch

@@ -1,0 +1,134 @@
+"""Runs a Whisper-Finetune script UNCHANGED on the MI355X front end:
+
+    python -m wfe_amd.launch finetune.py --base_model openai/whisper-large-v3 ...
+    torchrun --nproc_per_node=8 -m wfe_amd.launch finetune.py ...
+
+What it does, in this process and before anything touches a GPU:
+
+  * ``utils.reader`` and ``utils.data_utils`` -- exactly those two module names -- resolve to
+    this package's CustomDataset / collators / text helpers (the reference imports them at
+    finetune.py:11,13, finetune_all.py:11,13, evaluation.py:13,15; its own utils/data_utils.py
+    defines none of the names it is asked for).  Every other ``utils.*`` module
+    (utils.callback, utils.model_utils, utils.utils, utils.binary ...) and the ``utils``
+    package itself keep coming from the script's own tree: the script's directory is put at
+    ``sys.path[0]`` exactly as ``python script.py`` does.
+  * ``--num_workers 0`` is injected (or an explicit other value replaced, loudly) for scripts
+    that import the dataset / collator: the collator runs the fused HIP launch, and a forked
+    DataLoader worker cannot use the GPU (finetune.py:26,129 and evaluation.py:24,64-65
+    default to 8).  Host decode is parallelised inside CustomDataset.__getitems__ instead.
+  * with ``WFE_INSTALL_EXTRACTOR=1``, ``WhisperProcessor.from_pretrained`` returns a
+    processor whose feature extractor is the MI355X one (infer_tfs.py:27-37, evaluation.py:41-46).
+
+The script then runs in-process (``runpy.run_path``, ``__name__ == "__main__"``): no re-exec,
+so a torchrun-launched rank stays the process torchrun started.
+"""
+from __future__ import annotations
+
+import importlib.abc
+import importlib.machinery
+import os
+import runpy
+import sys
+
+_REDIRECTED = {
+    "utils.reader": ("CustomDataset",),
+    "utils.data_utils": ("DataCollatorSpeechSeq2SeqWithPadding", "DataCollatorSpeechSeq2SeqWithPaddingforEval",
+                         "remove_punctuation", "to_simple", "to_lower"),
+}
+
+
+class _Redirect(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    """Meta-path finder + loader for the two redirected names; nothing else is touched."""
+
+    def find_spec(self, fullname, path=None, target=None):
+        if fullname in _REDIRECTED:
+            return importlib.machinery.ModuleSpec(fullname, self, origin="wfe_amd.data")
+        return None
+
+    def create_module(self, spec):
+        return None
+
+    def exec_module(self, module):
+        from . import data
+        for name in _REDIRECTED[module.__name__]:
+            setattr(module, name, getattr(data, name))
+        module.__file__ = data.__file__
+        module.__wfe_amd__ = True
+
+
+def install_redirect() -> None:
+    if not any(isinstance(f, _Redirect) for f in sys.meta_path):
+        sys.meta_path.insert(0, _Redirect())
+
+
+def _uses_front_end(script_path: str) -> bool:
+    try:
+        with open(script_path, "r", encoding="utf-8", errors="replace") as f:
+            text = f.read()
+    except OSError:
+        return False
+    return ("utils.reader" in text or "utils.data_utils" in text) and "num_workers" in text
+
+
+def force_num_workers_zero(argv: list, note=sys.stderr) -> list:
+    """argv of the script with ``--num_workers 0``; says why whenever it changes anything."""
+    reason = ("[wfe_amd.launch] --num_workers {} -> 0: the GPU collator runs in the rank's main process (a forked "
+              "DataLoader worker cannot use the GPU); host decode is threaded inside CustomDataset (WFE_DECODE_THREADS)")
+    out, i, seen = [], 0, False
+    while i < len(argv):
+        a = argv[i]
+        if a == "--num_workers" and i + 1 < len(argv):
+            seen = True
+            if argv[i + 1] != "0":
+                print(reason.format(argv[i + 1]), file=note)
+            out += [a, "0"]
+            i += 2
+            continue
+        if a.startswith("--num_workers="):
+            seen = True
+            if a.split("=", 1)[1] != "0":
+                print(reason.format(a.split("=", 1)[1]), file=note)
+            out.append("--num_workers=0")
+            i += 1
+            continue
+        out.append(a)
+        i += 1
+    if not seen:
+        print(reason.format("(default 8)"), file=note)
+        out += ["--num_workers", "0"]
+    return out
+
+
+def _install_extractor_hook() -> None:
+    from transformers import WhisperProcessor
+    from .feature_extractor import install
+    original = WhisperProcessor.from_pretrained.__func__
+
+    def from_pretrained(cls, *args, **kwargs):
+        return install(original(cls, *args, **kwargs))
+    WhisperProcessor.from_pretrained = classmethod(from_pretrained)
+
+
+def main(argv=None) -> None:
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if not argv or argv[0] in ("-h", "--help"):
+        print(__doc__)
+        raise SystemExit(0 if argv else 2)
+    script = os.path.abspath(argv[0])
+    if not os.path.isfile(script):
+        raise SystemExit(f"wfe_amd.launch: no such script: {argv[0]}")
+    args = argv[1:]
+    if _uses_front_end(script):
+        args = force_num_workers_zero(args)
+    install_redirect()
+    if os.environ.get("WFE_INSTALL_EXTRACTOR", "0") == "1":
+        _install_extractor_hook()
+    # as `python script.py`: the script's directory leads sys.path, argv[0] is the script
+    script_dir = os.path.dirname(script)
+    sys.path.insert(0, script_dir)               # (-m put the cwd first; the script's directory goes ahead of it)
+    sys.argv = [script] + args
+    runpy.run_path(script, run_name="__main__")
+
+
+if __name__ == "__main__":
+    main()

@@ -40,8 +40,8 @@ def run_sharded(n_items: int, batch: int, make_batch: Callable[[int, int], tuple
 
     make_batch(begin, count) must derive utterance i from i alone (counter-based
     seeds), so that any sharding sees the same data.  checksum_stride > 1 sums every
-    stride-th element only (a throughput run should not spend a full extra read of the
-    output per batch on its own checksum)."""
+    stride-th element of each item only (a throughput run should not spend a full extra
+    read of the output per batch on its own checksum); still independent of the world size."""
     td = _dist()
     rank = (td.get_rank() if td else 0) if rank is None else rank
     world = (td.get_world_size() if td else 1) if world is None else world
@@ -60,7 +60,9 @@ def run_sharded(n_items: int, batch: int, make_batch: Callable[[int, int], tuple
     for b0 in range(begin, end, batch):
         count = min(batch, end - b0)
         out = transform(*make_batch(b0, count))
-        part = out if checksum_stride == 1 else out.reshape(-1)[::checksum_stride]
+        # sampled PER ITEM (every stride-th element of each utterance's features), so that the sum
+        # does not depend on where the batch boundaries of a sharding fall
+        part = out if checksum_stride == 1 else out.reshape(out.shape[0], -1)[:, ::checksum_stride]
         acc = acc.to(out.device) + part.sum(dtype=torch.float64)  # stays on the device; no host sync per batch
         done += count
     fence()
