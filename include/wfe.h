@@ -110,6 +110,23 @@ int wfe_mel_filters(wfe_handle h, double* host_out);
 int wfe_logmel(wfe_handle h, const float* wav, const int64_t* offsets, const int32_t* lengths,
                int64_t row_stride, int32_t batch, int32_t n_samples, float* out, void* stream);
 
+/* wfe_logmel for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for
+ * callers that must not reach hipMalloc / hipFree -- code under HIP graph capture, tight
+ * serving loops, harnesses that forbid allocation.  Same arguments, same kernels and bit for
+ * bit the same output as wfe_logmel (it honours wfe_set_output_format too); the per-tile
+ * statistics the first kernel leaves for the clamp kernel live in a static device array of the
+ * library (577 536 bytes, held on every GPU the library runs on until the process ends) instead
+ * of the handle's workspace, and the call itself allocates nothing, creates no event and is
+ * never timed by wfe_kernel_timing.
+ *   limit   batch * ceil((n_samples / 160) / 64) <= 12032 tiles (256 utterances of 30 s) and
+ *           batch <= 4096; anything larger is WFE_ERR_ARG with the numbers in wfe_last_error.
+ *   sharing every call on one GPU -- whatever the handle or stream -- uses that GPU's one array:
+ *           calls that overlap on a GPU race; order them on one stream or with events.  The
+ *           array keeps the last call's contents; nothing has to start at zero (kernel 1
+ *           writes all 12 statistics of every tile before the clamp kernel reads them). */
+int wfe_logmel_static(wfe_handle h, const float* wav, const int64_t* offsets, const int32_t* lengths,
+                      int64_t row_stride, int32_t batch, int32_t n_samples, float* out, void* stream);
+
 /* Same transform with the augmentation chain of CustomDataset.augment
  * (utils/reader.py:246-278) applied to each utterance while it is staged:
  * utterance b runs ops[op_begin[b] .. op_begin[b+1]).  `lengths` are the RAW

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -54,6 +55,16 @@ namespace {
 
 constexpr int kMaxBatchPerLaunch = 4096;
 thread_local std::string g_create_err;
+
+// ---- wfe_logmel_static's scratch (include/wfe.h): the per-tile statistics kernel 1 leaves for
+// kernel 2, for callers that cannot allocate.  One copy of the array per GPU, at its own address;
+// host code never uses the array's name as an address, only the pointer hipGetSymbolAddress
+// returned for the device (g_scratch_ptr, filled by wfe_create with that device current).
+constexpr int kStaticTiles = 256 * 47;           // 256 utterances of 30 s (47 tiles of 64 frames each)
+static __device__ __align__(256) float scratch[kStaticTiles * wfe::kTileStats];   // 577 536 bytes
+constexpr int kMaxDevices = 64;
+float* g_scratch_ptr[kMaxDevices] = {};
+std::mutex g_scratch_mu;
 
 // workspace sizes that wfe_create provides up front, so that the hot path of ordinary batches
 // never reaches hipFree / hipMalloc (larger requests still grow on demand)
@@ -307,6 +318,15 @@ int wfe_create(const wfe_config* cfg, wfe_handle* out) {
   if (e == hipSuccess) e = hipMalloc(&h->d_noise_meansq, kInitNoise * wfe::kNoiseParts * sizeof(double));
   if (e == hipSuccess) h->noise_cap = kInitNoise;
   if (e == hipSuccess) e = hipMalloc(&h->d_peaks, sizeof(unsigned) * 2 * kMaxBatchPerLaunch);
+  // wfe_logmel_static: this device's copy of the static scratch array (once per device)
+  if (e == hipSuccess && cfg->device < kMaxDevices) {
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[cfg->device]) {
+      float* ptr = nullptr;
+      e = hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch));
+      if (e == hipSuccess) g_scratch_ptr[cfg->device] = ptr;
+    }
+  }
   if (e != hipSuccess) {
     fail(nullptr, WFE_ERR_HIP, "wfe_create: %s", hipGetErrorString(e));
     wfe_destroy(h);
@@ -390,6 +410,38 @@ int wfe_logmel(wfe_handle h, const float* wav, const int64_t* offsets, const int
                int32_t batch, int32_t n_samples, float* out, void* stream) {
   return run_frontend(h, wav, 0, offsets, lengths, row_stride, batch, n_samples, nullptr, nullptr, 0, nullptr, nullptr,
                       0, out, 0, stream);
+}
+
+// wfe_logmel for callers that cannot allocate: the same two kernels, their per-tile statistics in
+// this GPU's copy of the static `scratch` array instead of the handle's workspace.  No hipMalloc,
+// hipFree, event or host container on this path.
+int wfe_logmel_static(wfe_handle h, const float* wav, const int64_t* offsets, const int32_t* lengths,
+                      int64_t row_stride, int32_t batch, int32_t n_samples, float* out, void* stream_) {
+  int rc = check_common(h, wav, lengths, batch, n_samples, out);
+  if (rc != WFE_OK) return rc;
+  if (batch == 0) return WFE_OK;
+  if (offsets == nullptr && row_stride < 0) return fail(h, WFE_ERR_ARG, "negative row_stride");
+  const int T = n_samples / wfe::kHop;
+  const long long tiles = (long long)batch * ((T + wfe::kBlockFrames - 1) / wfe::kBlockFrames);
+  if (batch > kMaxBatchPerLaunch || tiles > kStaticTiles)
+    return fail(h, WFE_ERR_ARG,
+                "wfe_logmel_static: batch %d x %d tiles of 64 frames = %lld tiles exceeds the static scratch "
+                "(%d tiles = 256 utterances of 30 s; at most %d utterances): split the batch or use wfe_logmel",
+                batch, (T + wfe::kBlockFrames - 1) / wfe::kBlockFrames, tiles, kStaticTiles, kMaxBatchPerLaunch);
+  if (h->cfg.device >= kMaxDevices || !g_scratch_ptr[h->cfg.device])
+    return fail(h, WFE_ERR_HIP, "wfe_logmel_static: no scratch address for device %d", h->cfg.device);
+  float* const stats = g_scratch_ptr[h->cfg.device];      // never the array's name: that is not a device address
+  hipStream_t stream = static_cast<hipStream_t>(stream_);
+  DeviceGuard guard(h->cfg.device);
+  if (!guard.ok) return fail(h, WFE_ERR_HIP, "hipSetDevice(%d) failed", h->cfg.device);
+  wfe::FrontArgs a;
+  fill_args(h, a, wav, 0, offsets, lengths, row_stride, n_samples);
+  a.tile_stats = stats;      // every tile's 12 statistics are written by kernel 1 before kernel 2 reads them: nothing to clear
+  a.out = out;
+  a.out_kind = h->out_kind;
+  HIP_TRY(h, wfe::launch_frontend(a, batch, 0, false, h->bank, stream));
+  HIP_TRY(h, wfe::launch_clamp(a.out, a.out_kind, stats, batch, h->cfg.n_mel, T, stream));
+  return WFE_OK;
 }
 
 int wfe_power_spectrum(wfe_handle h, const float* wav, const int64_t* offsets, const int32_t* lengths,

@@ -39,6 +39,7 @@ SYMBOLS = {
     "wfe_last_error": (C.c_char_p, [_P]),
     "wfe_mel_filters": (C.c_int, [_P, _P]),
     "wfe_logmel": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
+    "wfe_logmel_static": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
     "wfe_power_spectrum": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P]),
     "wfe_augment_logmel": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int64,
                                      _P, _P, C.c_int32, _P, _P]),
