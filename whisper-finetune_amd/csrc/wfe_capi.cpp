@@ -49,7 +49,6 @@ struct wfe_context {
   unsigned long long* d_stamps = nullptr;   // diagnostic builds only (wfe_debug_stamps)
   int out_kind = WFE_OUT_F32;               // wfe_set_output_format
   int tune = 0;                             // WFE_TUNE (experiments)
-  int n_cus = 256;                          // multiProcessorCount: workgroups of the persistent kernel
   std::string err;
 };
 
@@ -254,10 +253,7 @@ int run_frontend(wfe_context* h, const void* wav, int channels, const int64_t* o
       h->ev_used += 3;
       HIP_TRY(h, hipEventRecord(ev[0], stream));
     }
-    // log-mel of the two Whisper banks without augmentation: the resident-table kernel
-    const bool resident = mode == 0 && !aug && h->bank != 0 && (h->tune & 16);      // experiment, off by default
-    if (resident) HIP_TRY(h, wfe::launch_frontend_r(a, s.count, h->bank, h->n_cus, stream));
-    else HIP_TRY(h, wfe::launch_frontend(a, s.count, mode, aug, h->bank, stream));
+    HIP_TRY(h, wfe::launch_frontend(a, s.count, mode, aug, h->bank, stream));
     if (ev) HIP_TRY(h, hipEventRecord(ev[1], stream));
     if (mode == 0)
       HIP_TRY(h, wfe::launch_clamp(a.out, kind, h->d_tile_stats, s.count, h->cfg.n_mel, T, stream));
@@ -293,12 +289,10 @@ int wfe_create(const wfe_config* cfg, wfe_handle* out) {
   if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
     return fail(nullptr, WFE_ERR_HIP, "device %d is %s; this library is built for gfx950 only", cfg->device,
                 prop.gcnArchName);
-  const int n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 
   wfe_context* h = new (std::nothrow) wfe_context();
   if (!h) return fail(nullptr, WFE_ERR_ALLOC, "out of host memory");
   h->cfg = *cfg;
-  h->n_cus = n_cus;
   if (const char* t = std::getenv("WFE_TUNE")) h->tune = std::atoi(t);
   h->mel_filters.resize((size_t)wfe::kNfreq * cfg->n_mel);
   wfe_build_mel_filters(cfg->n_mel, h->mel_filters.data());
@@ -448,9 +442,7 @@ int wfe_logmel_static(wfe_handle h, const float* wav, const int64_t* offsets, co
   a.tile_stats = stats;      // every tile's 12 statistics are written by kernel 1 before kernel 2 reads them: nothing to clear
   a.out = out;
   a.out_kind = h->out_kind;
-  const bool resident = h->bank != 0 && (h->tune & 16);
-  if (resident) HIP_TRY(h, wfe::launch_frontend_r(a, batch, h->bank, h->n_cus, stream));
-  else HIP_TRY(h, wfe::launch_frontend(a, batch, 0, false, h->bank, stream));
+  HIP_TRY(h, wfe::launch_frontend(a, batch, 0, false, h->bank, stream));
   HIP_TRY(h, wfe::launch_clamp(a.out, a.out_kind, stats, batch, h->cfg.n_mel, T, stream));
   return WFE_OK;
 }

@@ -63,9 +63,6 @@ hipError_t launch_frontend(const FrontArgs& a, int batch, int mode, bool augment
 // max(stored, g(max-8)) over the tiles whose minimum is below max-8 (kernel 1 stored g(v) = (v+4)/4)
 hipError_t launch_clamp(float* out, int out_kind, const float* tile_stats, int batch, int n_mel, int n_frames,
                         hipStream_t stream);
-// log-mel of the two Whisper banks without augmentation: persistent, twiddles resident in registers
-// (same tile statistics)
-hipError_t launch_frontend_r(const FrontArgs& a, int batch, int bank, int n_cus, hipStream_t stream);
 // partial sums of squares of the noise clips: meansq has n_noise x kNoiseParts doubles
 constexpr int kNoiseParts = 16;
 hipError_t launch_noise_meansq(const float* noise, const long long* noise_off, int n_noise, double* meansq,

@@ -35,8 +35,6 @@
 // float64 and rounded once.
 #include <hip/hip_runtime.h>
 
-#include <type_traits>
-
 #include "wfe_kernels.h"
 #include "wfe_layout.h"
 
@@ -60,6 +58,7 @@ constexpr int kStampRow = 16;   // 0..5 phase boundaries, 6 hardware id, 7 k-loo
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x3 = __attribute__((ext_vector_type(3))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 // two consecutive floats at any 4-byte boundary: one global_load_dwordx2 (the memory pipe
 // spends ~16 cycles per wave on ANY per-lane-addressed load, so fewer, wider loads)
 typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
@@ -921,18 +920,26 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
 
   // k-steps 0 and 1 of the twiddle table (8 KB each): in flight while the
   // waveform is staged, then parked in the two LDS slots
-  const f32x4* __restrict__ gtab = reinterpret_cast<const f32x4*>(a.dft_tab) + tid;
+  // (through a buffer resource: the per-k-step offset rides in an SGPR, the lane offset is one VGPR for
+  // the whole kernel -- a global_load of base + constant beyond the 12-bit immediate costs a 64-bit VALU
+  // add per k-step, and VALU instructions are what the matrix pipe waits for)
+  const __amdgpu_buffer_rsrc_t tw_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dft_tab), 0, (int)(kDftTableFloats * 4), 0x00020000);
+  const int tw_lane = tid * 16;
+  auto tw_load = [&](int f4_index) {       // float4 number f4_index + tid of the table
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(tw_rsrc, tw_lane, f4_index * 16, 0));
+  };
   f32x4* const slots = reinterpret_cast<f32x4*>(lds + kLdsWaveFloats);       // 2 x 512 float4
   f32x4 g0, g1, g2, g3;
   // three staging sets in rotation: the twiddles of step s+4 are requested in step s and
   // parked in LDS in step s+2 (two whole steps for the L2 round trip under load)
   f32x4 G[3][2];
   auto request_twiddles = [&]() {
-    g0 = gtab[0], g1 = gtab[256], g2 = gtab[512], g3 = gtab[768];
-    G[1][0] = gtab[1024];                  // A(2), written out in step 0
-    G[1][1] = gtab[1280];
-    G[2][0] = gtab[1536];                  // A(3), written out in step 1
-    G[2][1] = gtab[1792];
+    g0 = tw_load(0), g1 = tw_load(256), g2 = tw_load(512), g3 = tw_load(768);
+    G[1][0] = tw_load(1024);               // A(2), written out in step 0
+    G[1][1] = tw_load(1280);
+    G[2][0] = tw_load(1536);               // A(3), written out in step 1
+    G[2][1] = tw_load(1792);
     G[0][0] = G[1][0];
     G[0][1] = G[1][1];
   };
@@ -1090,22 +1097,8 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) sample_request(0, i >> 1, i & 1);
   __syncthreads();      // slot 0 is overwritten in the middle of step 0: every wave must have read it out
-  const int prio_bias = (a.tune & 2) ? (int)(blockIdx.x & 1) : 0;
 #pragma unroll
   for (int s = 0; s < kSteps; ++s) {
-    if ((a.tune & 1) && (s % 9) == 0) {
-      // priority by progress: of the two waves a SIMD holds, the one further into its k-loop wins
-      // the matrix pipe, so that the two k-loops run one after the other instead of side by side
-      if (prio_bias) {
-        if (s == 0) __builtin_amdgcn_s_setprio(1);
-        if (s == 9) __builtin_amdgcn_s_setprio(2);
-        if (s == 18) __builtin_amdgcn_s_setprio(3);
-      } else {
-        if (s == 0) __builtin_amdgcn_s_setprio(0);
-        if (s == 9) __builtin_amdgcn_s_setprio(1);
-        if (s == 18) __builtin_amdgcn_s_setprio(2);
-      }
-    }
     Frag7(&Rc)[4] = (s & 1) ? Rb : Ra;
     Frag7(&Rn)[4] = (s & 1) ? Ra : Rb;
     const bool next = s + 1 < kSteps, stage = s + 2 < kSteps;
@@ -1126,9 +1119,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
     // them between two MFMAs idles the matrix pipe for the clump's issue time)
     auto request = [&](int i) {
       if (i < 2) {                                          // global -> registers, A(s+3)
-        // uniform base + 32-bit thread offset: a scalar-base load, no 64-bit VALU address math
-        if (s + 4 < kSteps)
-          Gr[i] = reinterpret_cast<const f32x4*>(a.dft_tab)[(s + 4) * 512 + 256 * i + (unsigned)tid];
+        if (s + 4 < kSteps) Gr[i] = tw_load((s + 4) * 512 + 256 * i);
       } else if (i < 4) {                                   // registers -> LDS, A(s+2)
         if (stage) slots[(s & 1) * 512 + 256 * (i - 2) + tid] = Gw[i - 2];
       } else if (i < 12) {                                  // LDS -> registers, fragments of A(s+1)
@@ -1163,10 +1154,6 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
 #endif
   }
 
-  if (a.tune & 1) {
-    if (a.tune & 4) __builtin_amdgcn_s_setprio(3);
-    else __builtin_amdgcn_s_setprio(0);
-  }
   WFE_STAMP(3);
 #ifdef WFE_STAMPS
   if (a.stamps && lane == 0)
@@ -1175,7 +1162,9 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   // Mel weight fragments of every live (bin tile, mel tile) block: all requested
   // here, ahead of the butterflies, so that the mel phase pays one L2 round trip
   // instead of one per block (the scheduling barrier pins the batch).
-  const f32x4* __restrict__ mtab = reinterpret_cast<const f32x4*>(a.mel_tab) + lane;
+  // (buffer loads for the same reason as the twiddles: block offset in an SGPR, no VALU address math)
+  const __amdgpu_buffer_rsrc_t mel_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.mel_tab), 0, (int)(kMelTableFloats * 4), 0x00020000);
   f32x4 wv[2][7][NMT];
   if (!POWER && BANK != 0) {
 #pragma unroll
@@ -1185,17 +1174,32 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
 #pragma unroll
         for (int mt = 0; mt < NMT; ++mt)
           if (((BANK == 1 ? kMelMask80[f * 7 + bt] : kMelMask128[f * 7 + bt]) >> mt) & 1u)
-            wv[f][bt][mt] = mtab[((f * 7 + bt) * kMelTiles + mt) * 64];
+            wv[f][bt][mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                mel_rsrc, lane * 16, ((f * 7 + bt) * kMelTiles + mt) * 64 * 16, 0));
     __builtin_amdgcn_sched_barrier(0);
   }
   // ---- butterflies + power: family 0 = bin k, family 1 = bin 200 - k
+  // (on register PAIRS where hipcc agrees: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 do two values per
+  // instruction, and every VALU instruction next to the partner wave's MFMA stream costs the matrix
+  // pipe 5..9 cycles -- tools/micro/mfma_issue.hip.  The same arithmetic spelled as inline-asm packed
+  // instructions packs every pair but reads accumulators behind the hazard recognizer's back: wrong
+  // results even behind explicit wait states, so the compiler-visible form stays.)
   f32x4 P[2][7];
 #pragma unroll
   for (int bt = 0; bt < 7; ++bt) {
-    const f32x4 ce = acc[0][bt], se = acc[1][bt], co = acc[2][bt], so = acc[3][bt];
-    const f32x4 rp = ce + co, ip = se + so, rm = ce - co, im = se - so;
-    P[0][bt] = rp * rp + ip * ip;
-    P[1][bt] = rm * rm + im * im;
+    f32x2 p0[2], p1[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const f32x2 ce = hh ? __builtin_shufflevector(acc[0][bt], acc[0][bt], 2, 3) : __builtin_shufflevector(acc[0][bt], acc[0][bt], 0, 1);
+      const f32x2 se = hh ? __builtin_shufflevector(acc[1][bt], acc[1][bt], 2, 3) : __builtin_shufflevector(acc[1][bt], acc[1][bt], 0, 1);
+      const f32x2 co = hh ? __builtin_shufflevector(acc[2][bt], acc[2][bt], 2, 3) : __builtin_shufflevector(acc[2][bt], acc[2][bt], 0, 1);
+      const f32x2 so = hh ? __builtin_shufflevector(acc[3][bt], acc[3][bt], 2, 3) : __builtin_shufflevector(acc[3][bt], acc[3][bt], 0, 1);
+      const f32x2 rp = ce + co, ip = se + so, rm = ce - co, im = se - so;
+      p0[hh] = __builtin_elementwise_fma(rp, rp, ip * ip);
+      p1[hh] = __builtin_elementwise_fma(rm, rm, im * im);
+    }
+    P[0][bt] = __builtin_shufflevector(p0[0], p0[1], 0, 1, 2, 3);
+    P[1][bt] = __builtin_shufflevector(p1[0], p1[1], 0, 1, 2, 3);
   }
   const int frame = t0 + wave * 16 + jl;
 
@@ -1260,23 +1264,44 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   // The value stored is already (v + 4) / 4: that map is monotone, so the max-8 clamp
   // of kernel 2 commutes with it exactly, max(g(v), g(max-8)) == g(max(v, max-8)), and
   // kernel 2 only has to touch the workgroups whose minimum lies below max-8.
-  float wmax = -INFINITY, wmin = INFINITY;
+  // Statistics on the POWER: log10 with its floor is monotone, so max / min of the log values are the
+  // log values of the max / min powers, exactly -- three-input max / min over the accumulators, then
+  // the log of two wave-uniform numbers, instead of two instructions per value.
   const bool frame_ok = frame < T;
+  auto log10_floor = [](float pw) {
+    return (pw > 1e-10f) ? __builtin_amdgcn_logf(pw) * 0.30102999566398120f : -10.0f;
+  };
+  float pmax = -INFINITY, pmin = INFINITY;
+#pragma unroll
+  for (int mt = 0; mt < NMT; ++mt) {
+    float hi = __builtin_fmaxf(__builtin_fmaxf(m[mt][0], m[mt][1]), m[mt][2]);      // v_max3_f32
+    float lo = __builtin_fminf(__builtin_fminf(m[mt][0], m[mt][1]), m[mt][2]);      // v_min3_f32
+    float hi3 = m[mt][3], lo3 = m[mt][3];
+    if (BANK == 0) {                                   // another feature_size: rows at and beyond n_mel do not count
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool live = 16 * mt + 4 * kk + r < a.n_mel;
+        if (r == 0) hi = live ? m[mt][0] : -INFINITY, lo = live ? m[mt][0] : INFINITY;
+        else if (r < 3) hi = live ? __builtin_fmaxf(hi, m[mt][r]) : hi, lo = live ? __builtin_fminf(lo, m[mt][r]) : lo;
+        else hi3 = live ? m[mt][3] : -INFINITY, lo3 = live ? m[mt][3] : INFINITY;
+      }
+    }
+    pmax = __builtin_fmaxf(__builtin_fmaxf(pmax, hi), hi3);
+    pmin = __builtin_fminf(__builtin_fminf(pmin, lo), lo3);
+  }
+  pmax = wave_reduce<true>(frame_ok ? pmax : -INFINITY);
+  pmin = wave_reduce<false>(frame_ok ? pmin : INFINITY);
+  // (a wave without a valid frame leaves -inf / +inf, as before)
+  const float wmax = pmax == -INFINITY ? -INFINITY : log10_floor(pmax);
+  const float wmin = pmin == INFINITY ? INFINITY : log10_floor(pmin);
 #pragma unroll
   for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int mel = 16 * mt + 4 * kk + r;
-      const float pw = m[mt][r];
-      const float v = (pw > 1e-10f) ? __builtin_amdgcn_logf(pw) * 0.30102999566398120f : -10.0f;
-      tile[mel * kTileStride + wave * 16 + jl] = (v + 4.0f) * 0.25f;
-      if (frame_ok && mel < a.n_mel) {
-        wmax = fmaxf(wmax, v);
-        wmin = fminf(wmin, v);
-      }
+      // (v + 4) / 4 as one fma: v / 4 + 1 rounds once, to the same float32 as (v + 4) * 0.25
+      tile[mel * kTileStride + wave * 16 + jl] = __builtin_fmaf(log10_floor(m[mt][r]), 0.25f, 1.0f);
     }
-  wmax = wave_reduce<true>(wmax);
-  wmin = wave_reduce<false>(wmin);
   if (lane == 0) {
     float* st = a.tile_stats + ((long long)b * nblk + blockIdx.x) * kTileStats;
     st[2 * wave] = wmin;                 // both entries of the frame group's pair
@@ -1332,492 +1357,6 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
     }
   }
   WFE_STAMP(5);
-}
-
-// ------------------------------------------------------------- kernel 1R
-// The resident-table form of kernel 1 (log-mel, the two Whisper banks, no augmentation).
-//
-// What bounded frontend_kernel (measured): its 4 waves share every k-step's
-// twiddles through LDS and meet at a barrier 25 times per tile; one wave per SIMD then reaches
-// 76 % of the matrix pipe in its k-loop, two resident waves 82 %, and the phases around the
-// k-loop run with the pipe half idle.  Here no twiddle moves after the prologue:
-//
-//   * ONE persistent workgroup of 8 waves per CU (two per SIMD) walks the tiles
-//     (64 frames of one utterance) with stride gridDim.x.
-//   * Waves 0..6 each own ONE bin tile of all four GEMMs (Ce, Se, Co, So) and keep its
-//     Hann-windowed twiddles -- 25 k-steps x 4 GEMMs = 100 registers -- resident for the whole
-//     launch.  A tile is four phases, one per 16-frame group: the wave streams the group's
-//     samples (four ds_read_b32 and four adds per k-step) through its 100 MFMAs -- no barrier,
-//     no LDS write inside the phase -- and, since it holds all four GEMMs of its bins, does
-//     the butterflies Ce+-Co, Se+-So and the power itself; 8 registers of power per lane go
-//     to an exchange buffer.  ONE barrier per phase.
-//   * Wave 7 owns no bins: it keeps the mel weights resident instead (18 | 21 blocks, in the
-//     same registers) and finishes the frame group of the PREVIOUS phase while the others
-//     multiply: 14 ds_read_b128 of power, the mel MFMAs in NMT interleaved chains, log10,
-//     (v + 4) / 4, statistics, and 64-byte row segments stored straight from the accumulator
-//     layout (the other half of each 128-byte line follows a phase later and meets it in L2).
-//     Its 72 | 84 MFMAs share SIMD 3 with wave 3's 100: 172 | 184 against 200 on the others.
-//   * S: the waveform image is streamed IN PLACE by all 512 lanes: the positions a phase has
-//     finished with are overwritten, during the next phase, with the next tile's samples,
-//     which were requested from HBM one phase earlier (truncation, zero and reflect padding,
-//     PCM conversion and mix-down as in frontend_kernel's gather path).
-//   Numerics: the DFT accumulators are bit for bit those of frontend_kernel (same k order);
-//   the mel sum runs over a tile's blocks in a fixed order -- every launch, every batch
-//   shape, the same order.  Tile statistics in frontend_kernel's layout (kTileStats).
-constexpr int kRThreads = 512;
-constexpr int kRExchFloats = 14 * 64 * 4;                          // one slot: [family][bin tile][lane][4] power
-constexpr int kRFoldFloats = 2 * 2 * kSteps * 64;                  // one slot: the B operands of one frame group
-constexpr int kRChunk = 16 * kHop;                                 // 2560 image positions per phase
-constexpr int kRMaxBlocks = 24;
-template <int BANK>
-struct MelBlocks {                                                 // the bank's non-zero (family, bin tile, mel tile) blocks
-  int n;
-  int f[kRMaxBlocks], bt[kRMaxBlocks], mt[kRMaxBlocks];
-  constexpr MelBlocks() : n(0), f{}, bt{}, mt{} {
-    // ordered so that consecutive blocks feed different mel tiles where possible (their MFMAs
-    // then do not wait for each other): rounds over the mel tiles, each taking its next block
-    int taken[2][7][8] = {};
-    bool more = true;
-    while (more) {
-      more = false;
-      for (int m = 0; m < 8; ++m) {
-        bool got = false;
-        for (int fam = 0; fam < 2 && !got; ++fam)
-          for (int b = 0; b < 7 && !got; ++b) {
-            const unsigned mask = BANK == 1 ? kMelMask80[fam * 7 + b] : kMelMask128[fam * 7 + b];
-            if (((mask >> m) & 1u) && !taken[fam][b][m] && n < kRMaxBlocks) {
-              taken[fam][b][m] = 1;
-              f[n] = fam, bt[n] = b, mt[n] = m;
-              ++n;
-              got = more = true;
-            }
-          }
-      }
-    }
-  }
-  constexpr bool complete() const {
-    int want = 0;
-    for (int i = 0; i < 14; ++i)
-      for (int m = 0; m < 8; ++m) want += ((BANK == 1 ? kMelMask80[i] : kMelMask128[i]) >> m) & 1u;
-    return n == want;
-  }
-};
-template <int BANK>
-__device__ constexpr MelBlocks<BANK> kMelBlocks{};
-static_assert(kMelBlocks<1>.complete() && kMelBlocks<2>.complete(), "more than kRMaxBlocks mel blocks");
-static_assert(kMelBlocks<1>.n <= kSteps && kMelBlocks<2>.n <= kSteps, "the mel weights share the twiddle registers");
-
-struct RTile {                 // uniform per workgroup
-  int id;                      // tile index b * nblk + tx, or -1
-  int b, tx, len;
-  Source src;
-};
-
-template <int NMT, int BANK>
-__global__ __launch_bounds__(kRThreads) void frontend_r_kernel(const FrontArgs a, const int total_tiles) {
-  __shared__ __attribute__((aligned(16))) float lds[kLdsWaveFloats + 2 * kRFoldFloats + 2 * kRExchFloats];
-  float* const img = lds;
-  float* const fold = lds + kLdsWaveFloats;                        // [slot 2][class 2][e | o][k-step 25][lane 64]
-  float* const exch = fold + 2 * kRFoldFloats;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);         // wave-uniform: scalar branches on the roles
-  const bool finisher = w == 7;
-  const int n = a.n_samples, T = a.n_frames;
-  const int nblk = (T + kBlockFrames - 1) / kBlockFrames;
-  const int jl = lane & 15, kk = lane >> 4;
-
-  // ---- resident registers: waves 0..6 the twiddles of bin tile w, [k-step][GEMM]; wave 7 the mel
-  // weights, one f32x4 per block
-  f32x4 R[kSteps];
-  if (!finisher) {
-    const float* __restrict__ tab = a.dft_tab + (w >> 2) * 256 + lane * 4 + (w & 3);
-#pragma unroll
-    for (int s = 0; s < kSteps; ++s)
-#pragma unroll
-      for (int gg = 0; gg < 4; ++gg) R[s][gg] = tab[(s * 4 + gg) * 512];
-  } else {
-#pragma unroll
-    for (int k = 0; k < kSteps; ++k) {
-      R[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (k < kMelBlocks<BANK>.n)
-        R[k] = reinterpret_cast<const f32x4*>(a.mel_tab)[((kMelBlocks<BANK>.f[k] * 7 + kMelBlocks<BANK>.bt[k]) * kMelTiles +
-                                                          kMelBlocks<BANK>.mt[k]) * 64 + lane];
-    }
-  }
-
-  // ---- tile walk: non-silent tiles only; the silent ones are marked on the way.  (b, tx) advance
-  // by the grid stride without a division.
-  const int step_b = gridDim.x / nblk, step_x = gridDim.x - step_b * nblk;
-  auto fill = [&](RTile& t) {
-    int len = a.lengths[t.b];
-    len = len < 0 ? 0 : len;
-    t.len = len > n ? n : len;                                     // truncation=True (HF:300-307)
-    t.src = make_source(a, t.b);
-  };
-  auto silent = [&](const RTile& t) {
-    const int i_first = t.tx * kBlockSamplesHop - kHalf, i_last = i_first + kBlockSamples - 1;
-    return i_first >= t.len && (i_last < n || 2 * (n - 1) - i_last >= t.len);
-  };
-  auto advance = [&](RTile t) {                                    // first non-silent tile after t (stride gridDim.x)
-    for (;;) {
-      t.id += gridDim.x;
-      t.b += step_b;
-      t.tx += step_x;
-      if (t.tx >= nblk) {
-        t.tx -= nblk;
-        ++t.b;
-      }
-      if (t.id >= total_tiles) {
-        t.id = -1;
-        return t;
-      }
-      fill(t);
-      if (!silent(t)) return t;
-      if (tid < kTileStats)                                        // -inf minima mark the tile for kernel 2
-        a.tile_stats[(long long)t.id * kTileStats + tid] = tid < 8 ? -INFINITY : -10.0f;
-    }
-  };
-
-#ifdef WFE_STAMPS
-  // diagnostic build: cycles per section summed over the phases of this wave
-  //   0 loop top -> 1 work before -> 2 finish | nothing -> 3 streaming -> 4 GEMM (waves 0..3) -> 5 barrier
-  unsigned long long racc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, rprev = 0, rphases = 0;
-#define RSTAMP(i)                                                                          \
-  do {                                                                                     \
-    unsigned long long t_;                                                                 \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");            \
-    if (rprev) racc[i] += t_ - rprev;                                                      \
-    rprev = t_;                                                                            \
-    if ((i) == 5) ++rphases;                                                               \
-  } while (0)
-#else
-#define RSTAMP(i) do {} while (0)
-#endif
-  // ---- S: streaming of the waveform image.  Chunk c = positions [2560 c, 2560 (c + 1)) (the last
-  // one to 10480) as groups of 4 consecutive positions (160 = 0 mod 4: a group never crosses a
-  // pad word), thread t takes groups t and t + 512.  Loads are raw (float bits / PCM integers)
-  // with a validity mask, so that nothing waits for them before the write one phase later.
-  int stg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned stg_ok = 0;
-  auto stage_load = [&](const RTile& t, int c) {
-    stg_ok = 0;
-    if (t.id < 0 || t.len <= 0) return;
-    const int p0 = t.tx * kBlockSamplesHop;
-    const int groups = (c == 3) ? (kBlockSamples - 3 * kRChunk) / 4 : kRChunk / 4;       // 700 | 640
-    const int i0 = p0 + kRChunk * c - kHalf;                       // sample index of the chunk's first position
-    const Source& sr = t.src;
-    // plain chunk: no reflection, no padding -- position q is sample p0 + q - 200
-    const bool plain = i0 >= 0 && i0 + 4 * groups <= t.len;
-    if (plain && !sr.pcm && (reinterpret_cast<uintptr_t>(sr.w + i0) & 15u) == 0) {
-      using i32x4 = __attribute__((ext_vector_type(4))) int;
-      const i32x4* __restrict__ v4 = reinterpret_cast<const i32x4*>(sr.w + i0);
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int gi = tid + kRThreads * u;
-        if (gi < groups) {
-          const i32x4 v = v4[gi];
-          stg[4 * u] = v[0], stg[4 * u + 1] = v[1], stg[4 * u + 2] = v[2], stg[4 * u + 3] = v[3];
-          stg_ok |= 0xfu << (4 * u);
-        }
-      }
-      return;
-    }
-    if (plain && sr.pcm && sr.ch == 1 && (reinterpret_cast<uintptr_t>(sr.pcm + i0) & 7u) == 0) {
-      const int2* __restrict__ v2 = reinterpret_cast<const int2*>(sr.pcm + i0);
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int gi = tid + kRThreads * u;
-        if (gi < groups) {
-          const int2 v = v2[gi];
-          stg[4 * u] = (int)(short)(v.x & 0xffff), stg[4 * u + 1] = v.x >> 16;
-          stg[4 * u + 2] = (int)(short)(v.y & 0xffff), stg[4 * u + 3] = v.y >> 16;
-          stg_ok |= 0xfu << (4 * u);
-        }
-      }
-      return;
-    }
-    int idx[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int gi = tid + kRThreads * (u >> 2);
-      const int q = kRChunk * c + 4 * gi + (u & 3);
-      const int i = gi < groups ? padded_index(q, p0, n, t.len) : -1;
-      stg_ok |= (i >= 0 ? 1u : 0u) << u;
-      idx[u] = i >= 0 ? i : 0;
-    }
-    if (!sr.pcm) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) stg[u] = __float_as_int(sr.w[idx[u]]);
-    } else if (sr.ch == 1) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) stg[u] = sr.pcm[idx[u]];
-    } else {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) stg[u] = __float_as_int(sr.at(idx[u]));
-    }
-  };
-  auto stage_write = [&](const RTile& t, int c) {
-    if (t.id < 0) return;
-    const int groups = (c == 3) ? (kBlockSamples - 3 * kRChunk) / 4 : kRChunk / 4;
-    const bool mono_pcm = t.src.pcm && t.src.ch == 1;
-    float v[8];
-    if (mono_pcm) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (float)stg[e] * (1.0f / 32768.0f);
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = __int_as_float(stg[e]);
-    }
-    if (stg_ok != 0xffu) {                                         // (boundary chunks only)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = ((stg_ok >> e) & 1u) ? v[e] : 0.f;
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int gi = tid + kRThreads * u;
-      if (gi < groups) {
-        float* dst = img + pad_q(kRChunk * c + 4 * gi);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) dst[e] = v[4 * u + e];
-      }
-    }
-  };
-
-  // ---- F: the folded samples of one frame group, e[n] = x[n] + x[400 - n] and o[n] = x[n] - x[400 - n],
-  // once per frame group for all seven GEMM waves -- a VALU instruction between two MFMAs costs the
-  // matrix pipe 5..8 cycles (tools/micro/mfma_issue.hip), so the GEMM stream itself holds none.
-  // Sample n = dft_n_of(class, s, kk) of frame j sits at image word 161 j + n + n / 160, its mirror
-  // 400 - n at 161 j + (400 - n) + (400 - n) / 160.  Per lane that is ONE byte offset per direction
-  // plus a compile-time immediate per k-step; the n / 160 term is a constant of the step except in
-  // the five steps whose four k-lanes straddle 160 (forward) or 320 (mirror).  Wave w folds class
-  // w & 1 (even | odd n) for the k-steps s = w >> 1 (mod 4).
-  const int fc0 = (w & 1) ? 1 : 2;
-  const int dsum = 2 * (kk >> 1) + 16 * (kk & 1) + fc0;            // n - nb(s), s < 24: 1..20
-  const int dtail = 2 * kk + fc0;                                  // n - 192, s = 24
-  const char* const img_b = reinterpret_cast<const char*>(img);
-  auto ld = [&](int byte_off, int imm) { return *reinterpret_cast<const float*>(img_b + byte_off + imm); };
-  auto fold_steps = [&](auto q_tag, int p, int slot) {
-    constexpr int Q = decltype(q_tag)::value;                      // k-steps s = Q (mod 4)
-    const int row_b = 4 * 161 * (16 * p + jl);
-    const int f_off = row_b + 4 * dsum, b_off = row_b + 4 * (kNfft / 2 + 1 - dsum);       // mirror: + 4 (200 - nb)
-    const int ft_off = row_b + 4 * (dtail + 1), bt_off = row_b + 4 * (kNfft / 2 + 1 - dtail);
-    float* dst = fold + slot * kRFoldFloats + (w & 1) * (2 * kSteps * 64) + lane;
-    constexpr int kN = (kSteps - Q + 3) / 4;                       // 7 | 6 | 6 | 6 steps
-    float xf[kN], xb[kN];
-#pragma unroll
-    for (int i = 0; i < kN; ++i) {
-      const int s = Q + 4 * i;
-      if (s == kSteps - 1) {
-        xf[i] = ld(ft_off, 4 * 192);                               // n >= 193: one pad word
-        xb[i] = ld(bt_off, 4 * (200 - 192));                       // 400 - n in 200..207: one pad word (in the base)
-      } else {
-        const int nb = 32 * (s >> 2) + 4 * (s & 3);
-        if (nb + 1 >= kHop) xf[i] = ld(f_off, 4 * (nb + 1));
-        else if (nb + 20 < kHop) xf[i] = ld(f_off, 4 * nb);
-        else xf[i] = ld(f_off + ((dsum + nb >= kHop) ? 4 : 0), 4 * nb);
-        if (nb + 20 <= 80) xb[i] = ld(b_off, 4 * (200 - nb + 1));  // x[400 - n]: 400 - n >= 320 <=> n <= 80
-        else if (nb + 1 > 80) xb[i] = ld(b_off, 4 * (200 - nb));
-        else xb[i] = ld(b_off + ((dsum + nb <= 80) ? 4 : 0), 4 * (200 - nb));
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < kN; ++i) {
-      const int s = Q + 4 * i;
-      dst[s * 64] = xf[i] + xb[i];
-      dst[(kSteps + s) * 64] = xf[i] - xb[i];
-    }
-  };
-  auto fold_group = [&](int p, int slot) {
-    switch (w >> 1) {
-      case 0: fold_steps(std::integral_constant<int, 0>{}, p, slot); break;
-      case 1: fold_steps(std::integral_constant<int, 1>{}, p, slot); break;
-      case 2: fold_steps(std::integral_constant<int, 2>{}, p, slot); break;
-      default: fold_steps(std::integral_constant<int, 3>{}, p, slot); break;
-    }
-  };
-
-  // ---- B: one frame group through this wave's four GEMMs, butterflies and power
-  constexpr int kAhead = 3;                                        // k-steps between an operand read and its use
-  auto gemm = [&](int slot) {
-    const float* src = fold + slot * kRFoldFloats + lane;
-    auto opnd = [&](int s, int which) { return src[(which * kSteps + s) * 64]; };   // 0 e even, 1 o even, 2 e odd, 3 o odd
-    f32x4 acc[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // reads run kAhead k-steps ahead of their use (pinned: hipcc otherwise sinks them to the use)
-    float bq[kAhead][4];
-#pragma unroll
-    for (int d = 0; d < kAhead; ++d)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) bq[d][j] = opnd(d, j);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < kSteps; ++s) {
-      const int d = s % kAhead;
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(R[s][0], bq[d][0], acc[0], 0, 0, 0);      // Ce
-      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(R[s][1], bq[d][1], acc[1], 0, 0, 0);      // Se
-      acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(R[s][2], bq[d][2], acc[2], 0, 0, 0);      // Co
-      acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(R[s][3], bq[d][3], acc[3], 0, 0, 0);      // So
-      __builtin_amdgcn_sched_barrier(0);
-      if (s + kAhead < kSteps) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bq[d][j] = opnd(s + kAhead, j);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // butterflies + power: family 0 = bin k, family 1 = bin 200 - k
-    const f32x4 rp = acc[0] + acc[2], ip = acc[1] + acc[3], rm = acc[0] - acc[2], im = acc[1] - acc[3];
-    f32x4* e4 = reinterpret_cast<f32x4*>(exch + slot * kRExchFloats) + w * 64 + lane;
-    e4[0] = rp * rp + ip * ip;
-    e4[7 * 64] = rm * rm + im * im;
-  };
-
-  // ---- D (wave 7): frame group ft of tile t (the previous phase) from exchange slot `slot`
-  auto finish = [&](const RTile& t, int ft, int slot) {
-    const f32x4* e4 = reinterpret_cast<const f32x4*>(exch + slot * kRExchFloats) + lane;
-    f32x4 P[14];
-#pragma unroll
-    for (int i = 0; i < 14; ++i) P[i] = e4[i * 64];
-    f32x4 m[NMT];
-#pragma unroll
-    for (int mt = 0; mt < NMT; ++mt) m[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // block-major within a round of the mel tiles, r-major overall: consecutive MFMAs feed
-    // different accumulators
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int k = 0; k < kMelBlocks<BANK>.n; ++k) {
-        const int mt = kMelBlocks<BANK>.mt[k], pi = kMelBlocks<BANK>.f[k] * 7 + kMelBlocks<BANK>.bt[k];
-        if (mt < NMT) m[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(R[k][r], P[pi][r], m[mt], 0, 0, 0);
-      }
-    RSTAMP(6);
-    const int frame = t.tx * kBlockFrames + 16 * ft + jl;
-    const bool frame_ok = frame < T;
-    // (n_mel == 16 NMT for the two Whisper banks: every mel row of the accumulators is a real one.)
-    // Straight-line on purpose: a taken scalar branch costs tens of cycles here, and a branch per
-    // value (output type, row validity) made this section the longest of the phase.
-    float vmin = INFINITY, vmax = -INFINITY;
-    float gv[NMT][4];
-#pragma unroll
-    for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        // clamp(min=1e-10).log10() (HF:159); the floor is produced exactly, as in frontend_kernel
-        const float pw = m[mt][r];
-        const float v = (pw > 1e-10f) ? __builtin_amdgcn_logf(pw) * 0.30102999566398120f : -10.0f;
-        vmin = fminf(vmin, v);
-        vmax = fmaxf(vmax, v);
-        gv[mt][r] = (v + 4.0f) * 0.25f;
-      }
-    vmin = frame_ok ? vmin : INFINITY;
-    vmax = frame_ok ? vmax : -INFINITY;
-    const long long row0 = ((long long)t.b * a.n_mel + 4 * kk) * T + frame;
-    if (frame_ok) {
-      if (a.out_kind == 0) {
-        float* __restrict__ o32 = a.out + row0;
-#pragma unroll
-        for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o32[(long long)(16 * mt + r) * T] = gv[mt][r];
-      } else {
-        const bool bf = a.out_kind == 2;
-        unsigned short* __restrict__ o16 = reinterpret_cast<unsigned short*>(a.out) + row0;
-        if (bf) {
-#pragma unroll
-          for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o16[(long long)(16 * mt + r) * T] = (unsigned short)to16(gv[mt][r], true);
-        } else {
-#pragma unroll
-          for (int mt = 0; mt < NMT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o16[(long long)(16 * mt + r) * T] = (unsigned short)to16(gv[mt][r], false);
-        }
-      }
-    }
-    RSTAMP(7);
-    vmin = wave_reduce<false>(vmin);
-    vmax = wave_reduce<true>(vmax);
-    if (lane == 0) {
-      float* st = a.tile_stats + (long long)t.id * kTileStats;
-      st[2 * ft] = vmin;                   // both entries of the frame group's pair (frontend_kernel's layout)
-      st[2 * ft + 1] = vmin;
-      st[8 + ft] = vmax;
-    }
-  };
-
-  // ---- prologue: first tile's chunks 0..2 into the image, chunk 3 requested
-  RTile cur, prv;
-  {
-    const int b0 = (int)blockIdx.x / nblk;                         // one stride before the first tile: advance() starts there
-    cur.id = (int)blockIdx.x - (int)gridDim.x;
-    cur.b = b0 - step_b;
-    cur.tx = (int)blockIdx.x - b0 * nblk - step_x;
-    if (cur.tx < 0) {
-      cur.tx += nblk;
-      --cur.b;
-    }
-    cur.len = 0;
-    cur.src = Source{nullptr, nullptr, 1};
-  }
-  cur = advance(cur);
-  prv = cur;
-  prv.id = -1;
-#pragma unroll 1
-  for (int c = 0; c < 3; ++c) {
-    stage_load(cur, c);
-    stage_write(cur, c);
-  }
-  stage_load(cur, 3);
-  // the resident tables have arrived before the pipeline starts: nothing inside it then waits on
-  // vmcnt for them (the chunk and store traffic of a phase stays in flight across the GEMM)
-  __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0)
-  __syncthreads();
-  if (cur.id >= 0) fold_group(0, 0);
-  __syncthreads();
-
-  // ---- the phase pipeline.  Phase p of a tile: S writes chunk (p + 3) % 4 (requested one phase
-  // ago) and requests chunk p of the next tile; F folds frame group p + 1 (of the next tile after
-  // the last); waves 0..6 multiply frame group p; wave 7 finishes the frame group of the phase
-  // before.  Fold and exchange slots alternate with the phase parity.
-#pragma unroll 1
-  while (cur.id >= 0 || prv.id >= 0) {
-    const RTile nxt = cur.id >= 0 ? advance(cur) : cur;
-#pragma unroll 1
-    for (int p = 0; p < 4; ++p) {
-      const int slot = p & 1;
-      const bool has_b = cur.id >= 0 && !finisher && !(a.tune & 256);
-      const bool has_f = p < 3 ? cur.id >= 0 : nxt.id >= 0;          // the frame group after this one
-      const RTile& t1 = p >= 1 ? cur : prv;                          // phase p - 1: frame group (p + 3) % 4
-      RSTAMP(0);
-      // the two waves of a SIMD enter the phase in opposite order: one multiplies while the other does the rest
-      if (w >= 4 && has_b) gemm(slot);
-      RSTAMP(1);
-      if (finisher && t1.id >= 0 && !(a.tune & 64)) finish(t1, (p + 3) & 3, slot ^ 1);
-      RSTAMP(2);
-      if (has_f) fold_group((p + 1) & 3, slot ^ 1);
-      RSTAMP(8);
-      if (!(a.tune & 128)) {
-        stage_write(p == 0 ? cur : nxt, (p + 3) & 3);
-        RSTAMP(9);
-        stage_load(nxt, p);
-      }
-      RSTAMP(3);
-      if (w < 4 && has_b) gemm(slot);
-      RSTAMP(4);
-      __syncthreads();
-      RSTAMP(5);
-    }
-    prv = cur;
-    cur = nxt;
-  }
-#ifdef WFE_STAMPS
-  if (a.stamps && lane == 0) {
-    unsigned long long* st = a.stamps + ((long long)blockIdx.x * 8 + w) * 16;
-    for (int i = 0; i < 10; ++i) st[i] = racc[i];
-    st[10] = rphases;
-  }
-#endif
 }
 
 // ------------------------------------------------------------- kernel 2
@@ -2321,8 +1860,7 @@ __global__ __launch_bounds__(256) void reverb_scale_kernel(const ReverbArgs a) {
 template <int NMT, bool POWER, bool AUG, int BANK>
 static hipError_t launch_k1(const FrontArgs& a, int batch, hipStream_t stream) {
   const dim3 grid((a.n_frames + kBlockFrames - 1) / kBlockFrames, batch);
-  const size_t dyn = (a.tune & 8) ? 40960 : 0;     // experiment: one workgroup per CU
-  hipLaunchKernelGGL((frontend_kernel<NMT, POWER, AUG, BANK>), grid, dim3(256), dyn, stream, a);
+  hipLaunchKernelGGL((frontend_kernel<NMT, POWER, AUG, BANK>), grid, dim3(256), 0, stream, a);
   return hipGetLastError();
 }
 
@@ -2344,19 +1882,6 @@ hipError_t launch_clamp(float* out, int out_kind, const float* tile_stats, int b
                         hipStream_t stream) {
   const dim3 grid((n_frames + kBlockFrames - 1) / kBlockFrames, batch);
   hipLaunchKernelGGL(clamp_kernel, grid, dim3(256), 0, stream, out, out_kind, tile_stats, n_mel, n_frames);
-  return hipGetLastError();
-}
-
-// The resident-table kernel: one persistent workgroup per CU (its LDS footprint keeps a second one
-// off the CU).  bank 1 | 2 only.
-hipError_t launch_frontend_r(const FrontArgs& a, int batch, int bank, int n_cus, hipStream_t stream) {
-  const long long tiles = (long long)batch * ((a.n_frames + kBlockFrames - 1) / kBlockFrames);
-  const int grid = (int)(tiles < n_cus ? tiles : n_cus);
-  if (grid < 1) return hipSuccess;
-  if (bank == 1)
-    hipLaunchKernelGGL((frontend_r_kernel<5, 1>), dim3(grid), dim3(kRThreads), 0, stream, a, (int)tiles);
-  else
-    hipLaunchKernelGGL((frontend_r_kernel<8, 2>), dim3(grid), dim3(kRThreads), 0, stream, a, (int)tiles);
   return hipGetLastError();
 }
 

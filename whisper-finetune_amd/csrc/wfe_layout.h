@@ -59,7 +59,6 @@ constexpr unsigned kMelMask128[14] = {0x3, 0xe, 0x18, 0x30, 0x20, 0x60, 0x40,
 constexpr int kWaves = 4;
 constexpr int kBlockFrames = kWaves * 16;                           // 64
 constexpr int kBlockSamples = (kBlockFrames - 1) * kHop + kNfft;   // 10480 padded-signal positions
-constexpr int kBlockSamplesHop = kBlockFrames * kHop;              // 10240: first position of the next tile
 
 // LDS image of the waveform tile: position q -> q + q/160.  The extra word per
 // hop makes the 16 frames of an MFMA B operand (stride 160 = 0 mod 32 banks)
