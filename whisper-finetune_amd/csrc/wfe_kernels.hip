@@ -1406,15 +1406,17 @@ __global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ out, int
             uint2* q = reinterpret_cast<uint2*>(ph + (long long)mel * T + 4 * c4);
             uint2 v;
             v.x = v.y = hc | (hc << 16);
-            if (!silent) {
-              v = *q;
-              unsigned e[4] = {v.x & 0xffffu, v.x >> 16, v.y & 0xffffu, v.y >> 16};
+            if (silent) {
+              *q = v;
+            } else {
+              const uint2 old = *q;
+              unsigned e[4] = {old.x & 0xffffu, old.x >> 16, old.y & 0xffffu, old.y >> 16};
 #pragma unroll
               for (int j = 0; j < 4; ++j) e[j] = (from16(e[j], bf) > ff) ? e[j] : hf;
               v.x = e[0] | (e[1] << 16);
               v.y = e[2] | (e[3] << 16);
+              if (v.x != old.x || v.y != old.y) *q = v;      // (only where the clamp changes something)
             }
-            *q = v;
           }
         }
       } else {
@@ -1446,13 +1448,15 @@ __global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ out, int
         const int mel = idx >> 3, c4 = idx & 7;
         if (4 * c4 < frames_here) {
           f32x4* q = reinterpret_cast<f32x4*>(ph + (long long)mel * T + 4 * c4);
-          f32x4 v = f32x4{c, c, c, c};
-          if (!silent) {
-            v = *q;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], floor_g);
+          if (silent) {
+            *q = f32x4{c, c, c, c};
+          } else {
+            // written back only where the clamp changes something: a half tile is here because ONE of its
+            // values lies below the floor (often a single quiet mel row), the rest is read and left alone
+            const f32x4 v = *q;
+            if (fminf(fminf(v[0], v[1]), fminf(v[2], v[3])) < floor_g)
+              *q = f32x4{fmaxf(v[0], floor_g), fmaxf(v[1], floor_g), fmaxf(v[2], floor_g), fmaxf(v[3], floor_g)};
           }
-          *q = v;
         }
       }
     } else {
