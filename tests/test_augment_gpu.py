@@ -271,6 +271,74 @@ def test_shipped_shape_tiny_inputs(fe, n):
         assert not got[i, len(w):].any()
 
 
+def test_contiguous_staging_matches_gather_form(fe, monkeypatch):
+    """Kernel 1 stages the shipped chain shape in two forms: tiles without reflection or padding read
+    a contiguous run of source and noise with 16-byte loads (SPEED chains through an LDS pass, in three
+    chunks), everything else gathers per output position.  Both must produce the SAME BITS (same
+    resolved gains, same roundings in the same order), on the edges of the contiguous form: noise clips
+    of 1023 (falls back), 1024, 1027 (not a multiple of 4: lanes whose four samples straddle the end of
+    the clip), 2050, 70001 samples and one longer than the utterance; rates 0.9 / 1.1 / 1.33 (the limit of
+    the LDS pass) / 1.4 (falls back); shifts that push the first tiles below index 0 and the last beyond the
+    signal.  The gather form is then checked against the oracle as everywhere else."""
+    from wfe_amd import _lib
+    from wfe_amd.frontend import HipFrontEnd, NoiseBank, pack_ragged
+    bank = [(0.05 * np.random.default_rng(60 + j).standard_normal(n)).astype(np.float32)
+            for j, n in enumerate((1023, 1024, 1027, 2050, 70001, 131072))]
+    gain = float(np.float32(10. ** (-4 / 20.)))
+    waves, plans, want = [], [], []
+    k = 0
+    for j in range(len(bank)):
+        for rate in (None, 0.9, 1.1, 1.33, 1.4):
+            for shift_ms in (2, -3, -560):
+                n = 70000 + 4093 * (k % 5)
+                x = cases.bench_clip(200 + k, n)
+                start = min(11 + k, len(bank[j]) - n) if len(bank[j]) > n else 0
+                y = oa.add_noise(x.copy(), bank[j], 15 + k % 7, lambda a, b: start)      # noqa: B023
+                ops = [(_lib.AUG_NOISE, j, start, 15 + k % 7, 0.0)]
+                if rate is not None:
+                    y = oa.change_speed(y, rate)
+                    ops.append((_lib.AUG_SPEED, int(n / rate), 0, 0, 0.0))
+                y = oa.volume(oa.shift(y, 16000, shift_ms), -4)
+                ops += [(_lib.AUG_SHIFT, oa.shift_samples(shift_ms, 16000), 0, 0, 0.0), (_lib.AUG_VOLUME, 0, 0, -4, gain)]
+                waves.append(x)
+                plans.append(ops)
+                want.append(y)
+                k += 1
+    # speed / shift / volume only (bit-exact against the oracle)
+    n_exact = 0
+    for rate in (0.9, 1.1, 1.33):
+        x = cases.bench_clip(300 + n_exact, 90001)
+        waves.append(x)
+        plans.append([(_lib.AUG_SPEED, int(len(x) / rate), 0, 0, 0.0), (_lib.AUG_SHIFT, oa.shift_samples(2, 16000), 0, 0, 0.0),
+                      (_lib.AUG_VOLUME, 0, 0, -4, gain)])
+        want.append(oa.volume(oa.shift(oa.change_speed(x.copy(), rate), 16000, 2), -4))
+        n_exact += 1
+    n_samples = 110000
+    flat, off, lens = pack_ragged(waves, fe.device)
+    nb = NoiseBank(bank, fe.device)
+    wav, wl = fe.augment_waveform(flat, lens, plans, nb, n_samples=n_samples, offsets=off)
+    mel = fe.augment_logmel(flat, lens, plans, nb, n_samples=n_samples, offsets=off)
+    monkeypatch.setenv("WFE_TUNE", "1")                   # the gather form everywhere (read at wfe_create)
+    fe_g = HipFrontEnd(n_mel=80, device=0)
+    nb_g = NoiseBank(bank, fe_g.device)
+    wav_g, wl_g = fe_g.augment_waveform(flat, lens, plans, nb_g, n_samples=n_samples, offsets=off)
+    mel_g = fe_g.augment_logmel(flat, lens, plans, nb_g, n_samples=n_samples, offsets=off)
+    torch.cuda.synchronize()
+    assert torch.equal(wl, wl_g)
+    assert torch.equal(wav, wav_g), (wav - wav_g).abs().amax(dim=1).nonzero().flatten().tolist()
+    assert torch.equal(mel, mel_g), (mel - mel_g).abs().amax(dim=(1, 2)).nonzero().flatten().tolist()
+    wav = wav.cpu().numpy()
+    for i, w in enumerate(want):
+        kk = min(len(w), n_samples)
+        assert int(wl[i]) == len(w), (i, plans[i])
+        err = np.abs(wav[i, :kk] - w[:kk]).max()
+        if i >= len(want) - n_exact:
+            assert err == 0.0, (i, err)
+        else:
+            assert err <= NOISE_RTOL * max(np.abs(w).max(), 1e-30), (i, plans[i], err)
+        assert not wav[i, kk:].any()
+
+
 def _rir(seed, n):
     """A synthetic room impulse response: direct path + exponentially decaying noise."""
     rng = np.random.default_rng(seed)

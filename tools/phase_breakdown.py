@@ -60,12 +60,14 @@ print(f"{'  k-loop barrier waits':22s} median {np.median(s[:, 7]):9.0f}  (sum ov
 print(f"{'total':22s} median {np.median(tot):9.0f}  p10 {np.percentile(tot, 10):9.0f}  p90 {np.percentile(tot, 90):9.0f}")
 
 if os.environ.get("WFE_PHASE_AUG") == "1":           # slots 8..11 carry the staging passes of SPEED chains
-    t0, t1, t2, nb = s[:, 8], s[:, 9], s[:, 10], s[:, 11]
+    t0, t1, t2, nb, t3 = s[:, 8], s[:, 9], s[:, 10], s[:, 11], s[:, 12]
+    print("(WFE_TUNE & 1: gather form -- indices / gathers / arithmetic; else contiguous form of SPEED tiles -- "
+          "set-up + first fetch issue / wait + mix + LDS / next fetch issue + barrier / interpolation + barrier)")
     for nme, sel in (("tiles staged in >= 3 batches (SPEED)", nb >= 3), ("tiles staged in 2 batches", nb == 2), ("tiles staged in 1 batch", nb == 1)):
         if not sel.any():
             continue
         print(f"{nme}: {sel.sum()} of {len(s)} waves; staging phase median {np.median(d[sel, 0]):.0f}")
-        for lab, v in (("indices + noise addresses", t0), ("gathers (issue + wait)", t1), ("arithmetic + LDS writes", t2)):
+        for lab, v in (("part 0", t0), ("part 1", t1), ("part 2", t2), ("part 3", t3)):
             print(f"  {lab:26s} median {np.median(v[sel]):9.0f}  p10 {np.percentile(v[sel], 10):9.0f}  p90 {np.percentile(v[sel], 90):9.0f}")
     sys.exit(0)
 

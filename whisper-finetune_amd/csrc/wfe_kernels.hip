@@ -547,10 +547,17 @@ struct Ticker {
     acc[k] += t_ - prev;
     prev = t_;
   }
+  __device__ __forceinline__ void mark(int k) {          // as tick, without draining the loads in flight
+    unsigned long long t_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+    acc[k] += t_ - prev;
+    prev = t_;
+  }
   __device__ __forceinline__ void batch() { ++batches; }
 #else
   __device__ __forceinline__ void start() {}
   __device__ __forceinline__ void tick(int) {}
+  __device__ __forceinline__ void mark(int) {}
   __device__ __forceinline__ void batch() {}
 #endif
 };
@@ -736,9 +743,218 @@ __device__ __forceinline__ void stage_shipped(const Chain& c, const Shipped f, f
   }
 }
 
+// ---- the shipped chain over a float32 source, contiguous form.  stage_shipped above gathers per
+// OUTPUT position: ~50 VALU instructions each, and two 4- or 8-byte loads per position.  What that costs
+// (tools/phase_breakdown.py, tools/micro/vmem_issue.hip): a CU keeps only ~64 wave-level loads in flight, so
+// a tile's ~500 narrow loads are 8 dependent memory round trips of ~1.5k cycles however they are batched
+// -- the staging of a SPEED + NOISE tile ran 28k cycles on an otherwise EMPTY CU, as long as the whole
+// k-loop, and twice that next to the partner workgroup.  A tile without reflection or padding reads a
+// CONTIGUOUS run of the source, so here
+//   * source and noise travel as 16-byte loads through buffer resources (lane offset + immediate: no
+//     address arithmetic, no clamps): 11 + 11 loads per lane without SPEED, 3 x (5 + 5) with;
+//   * the np.pad-wrap index of the noise advances by 1024 per row with one unsigned min; the one lane in
+//     ~ln / 4 whose four samples straddle the end of the clip is redone sample by sample afterwards;
+//   * a SPEED chain mixes the noise ONCE per source sample into the (still unused) twiddle / output-tile
+//     area of LDS and interpolates from there with one ds_read2 per position, in three chunks of
+//     15 x 256 positions (3840 = 24 hops, so the image address is lane base + immediate throughout);
+//   * the image address uses five lane bases: pad_q(q + 1280) = pad_q(q) + 1288.
+// Same roundings in the same order as stage_shipped / chain_eval (tests: chain goldens).  Returns false
+// (nothing staged, no barrier passed) when the tile or the chain does not fit -- reflection, padding, the
+// end of the utterance inside the fetched run, 16-bit source, clips shorter than 1024 samples, rates above
+// 1.33 -- and the caller falls back to the gather form.
+constexpr int kChunkRows = 15;                 // output rows (256 positions each) per chunk
+constexpr int kSrcVecs = 5;                    // 16-byte source loads per lane and chunk: 5120 floats of LDS
+constexpr int kSrcFloats = kSrcVecs * 1024;
+constexpr int kStageAuxFloats = kSrcFloats + 64;
+constexpr int kImageRows = (kBlockSamples + 255) / 256;          // 41, the last holds 240 positions
+constexpr int kLastRowLanes = kBlockSamples - 256 * (kImageRows - 1);
+constexpr int kImageVecs = (kBlockSamples + 1023) / 1024;        // 11 rows of 256 x 4 positions without SPEED
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long uni(long long v) {
+  const unsigned lo = (unsigned)uni((int)(v & 0xffffffffll)), hi = (unsigned)uni((int)(v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+// floats [first, first + count) of p as a raw buffer: loads beyond it return 0 instead of faulting
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t f32_rsrc(const float* p, long long first, long long count) {
+  count = count < 0 ? 0 : (count > (1ll << 29) ? (1ll << 29) : count);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p + first), 0, (int)(count * 4), 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_f32x4(__amdgpu_buffer_rsrc_t r, int byte_offset) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_offset, 0, 0));
+}
+__device__ __forceinline__ int mod_clip(int s, int ln, double inv) {       // s mod ln, s >= 0, without the integer divide
+  const int qd = (int)((double)s * inv);
+  int r = s - qd * ln;
+  r = (r < 0) ? r + ln : r;
+  return (r >= ln) ? r - ln : r;
+}
+
+template <bool SPEED, bool NOISE>
+__device__ __forceinline__ bool stage_contiguous(const Chain& c, const Shipped f, float* __restrict__ lds,
+                                                 float* __restrict__ aux, int p0, int len, int tid, Ticker& tk) {
+  const int L0 = c.len0, last = L0 - 1, L1 = SPEED ? c.len1 : L0;
+  const int cur0 = p0 - kHalf + f.shift;          // position q is index cur0 + q of the chain's last segment
+  const COp nop = get_cop(c, NOISE ? f.noise_k : 0);
+  const int ln = NOISE ? uni(nop.ln) : 0, start = NOISE ? uni(nop.i1) : 0;
+  const bool wrap = NOISE && ln < L0;
+  const double step = c.step, dlast = (double)last;
+  auto src_of = [&](int cu) { return (int)fmin(mul_rn((double)cu, step), dlast); };
+  bool ok = c.src.w && L0 > 0 && p0 - kHalf >= 0 && p0 - kHalf + kBlockSamples <= len;
+  if (NOISE) ok = ok && (wrap ? ln >= 1024 : (start >= 0 && (long long)start + L0 <= ln));
+  if (SPEED) {
+    // every chunk's run of kSrcFloats source samples lies inside the utterance (the last chunk's starts furthest in)
+    const int first = cur0 + 256 * kChunkRows * ((kImageRows - 1) / kChunkRows);
+    ok = ok && L1 >= 1 && step >= 0.0 && step * (double)(kChunkRows * 256 - 1) + 3.0 <= (double)kSrcFloats &&
+         (long long)src_of(min(max(first, 0), L1 - 1)) + kSrcFloats <= L0;
+  } else {
+    ok = ok && cur0 >= 0 && (long long)cur0 + kImageVecs * 1024 <= L0;
+  }
+  if (!uni((int)ok)) return false;
+
+  const float* __restrict__ clip = c.noise + (NOISE ? uni(nop.o0) : 0ll);
+  const float ra = nop.ra, rb = nop.rb, gain = f.gain;
+  const double inv = nop.inv;
+  const int t16 = tid * 16;
+  const unsigned ln4 = (unsigned)ln * 4u;
+  // sample *= gain; noise *= gain; sample += noise: three float32 roundings (utils/reader.py:330-340)
+  auto mixed = [&](float x, float nz) { return NOISE ? add_rn(mul_rn(x, ra), mul_rn(nz, rb)) : x; };
+  // R rows (256 lanes x 4 samples) of the source from sample s0 on, and the noise that meets them.  A lane
+  // whose four noise samples would straddle the end of the clip reads the clip's last four instead and is
+  // counted in `split`.
+  bool split = false;
+  auto fetch = [&](auto& X, auto& NZ, int s0, auto rows) {
+    constexpr int R = decltype(rows)::value;
+    const __amdgpu_buffer_rsrc_t rx = f32_rsrc(c.src.w, s0, (long long)L0 - s0);
+#pragma unroll
+    for (int i = 0; i < R; ++i) X[i] = buf_f32x4(rx, t16 + 4096 * i);
+    if (NOISE) {
+      if (wrap) {                                   // np.pad(noise, 'wrap'): s mod ln, advanced by 1024 per row
+        const __amdgpu_buffer_rsrc_t rn = f32_rsrc(clip, 0, ln);
+        unsigned mb = (unsigned)mod_clip(s0 + 4 * tid, ln, inv) * 4u;
+        const unsigned top = ln4 - 16u;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+          split = split || mb > top;
+          NZ[i] = buf_f32x4(rn, (int)min(mb, top));
+          mb += 4096u;
+          mb = min(mb, mb - ln4);                   // ln >= 1024: at most one wrap per row
+        }
+      } else {                                      // the slice noise[start : start + L0]
+        const __amdgpu_buffer_rsrc_t rn = f32_rsrc(clip, (long long)s0 + start, (long long)ln - s0 - start);
+#pragma unroll
+        for (int i = 0; i < R; ++i) NZ[i] = buf_f32x4(rn, t16 + 4096 * i);
+      }
+    }
+  };
+  // the straddling lanes again, sample by sample (wave-uniform branch: taken by one wave in ~ln / 1024 rows);
+  // put(row, element, value) stores the mixed sample of source index s0 + 4 tid + 1024 row + element
+  auto redo_split = [&](int s0, int rows, auto put) {
+    if (!NOISE || !__builtin_amdgcn_ballot_w64(split)) return;
+    if (split) {
+      for (int i = 0; i < rows; ++i) {
+        const int s = s0 + 4 * tid + 1024 * i;
+        const int m = mod_clip(s, ln, inv);
+        if (m > ln - 4) {
+          for (int e = 0; e < 4; ++e) {
+            const int me = (m + e >= ln) ? m + e - ln : m + e;
+            put(i, e, mixed(s + e < L0 ? c.src.w[s + e] : 0.f, clip[me]));
+          }
+        }
+      }
+    }
+    split = false;
+  };
+
+  if (!SPEED) {
+    int pb[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) pb[r] = pad_q(4 * tid + 1024 * r);      // pad_q(q + 5120) = pad_q(q) + 5152
+    f32x4 X[kImageVecs], NZ[kImageVecs];
+    fetch(X, NZ, cur0, std::integral_constant<int, kImageVecs>{});
+    constexpr int kTailLanes = (kBlockSamples - 1024 * (kImageVecs - 1)) / 4;        // 60 lanes in the last row
+#pragma unroll
+    for (int row = 0; row < kImageVecs; ++row) {
+      if (row < kImageVecs - 1 || tid < kTailLanes) {
+        float* __restrict__ o = lds + pb[row % 5] + 5152 * (row / 5);     // 4 | 160: the four share q / 160
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = mul_rn(mixed(X[row][e], NZ[row][e]), gain);
+      }
+    }
+    redo_split(cur0, kImageVecs, [&](int i, int e, float v) {
+      const int q = 4 * tid + 1024 * i + e;
+      if (q < kBlockSamples) lds[pad_q(q)] = mul_rn(v, gain);
+    });
+    return true;
+  }
+
+  // SPEED: np.interp(np.linspace(0, len0, len1), arange(len0), seg0) at cur = position cur * step, clamped to
+  // the last sample (see stage_shipped).  Chunk k covers image rows [15 k, 15 k + rows).
+  int pb[5];
+#pragma unroll
+  for (int r = 0; r < 5; ++r) pb[r] = pad_q(tid + 256 * r);
+  auto image = [&](int row, float v) {            // position tid + 256 row of the image
+    if (row < kImageRows - 1 || tid < kLastRowLanes) lds[pb[row % 5] + 1288 * (row / 5)] = v;
+  };
+  f32x4 X[kSrcVecs], NZ[kSrcVecs];
+  struct Span { int lo, hi, jlo; };
+  auto span_of = [&](int k, int out_rows) {
+    const int first = cur0 + 256 * kChunkRows * k;
+    Span s;
+    s.lo = uni(min(max(first, 0), L1 - 1));
+    s.hi = uni(min(max(first + 256 * out_rows - 1, 0), L1 - 1));
+    s.jlo = uni(src_of(s.lo));                      // (src_of(hi) + 1 - jlo < kSrcFloats by the check on step above)
+    return s;
+  };
+  constexpr int kChunks = (kImageRows + kChunkRows - 1) / kChunkRows;       // 3
+  Span nxt = span_of(0, kChunkRows);
+  fetch(X, NZ, nxt.jlo, std::integral_constant<int, kSrcVecs>{});
+  tk.mark(0);
+#pragma unroll
+  for (int k = 0; k < kChunks; ++k) {
+    const Span s = nxt;
+    const int out_rows = (k + 1 < kChunks) ? kChunkRows : kImageRows - kChunkRows * k;
+#pragma unroll
+    for (int i = 0; i < kSrcVecs; ++i) {
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = mixed(X[i][e], NZ[i][e]);
+      *reinterpret_cast<f32x4*>(aux + 4 * tid + 1024 * i) = v;
+    }
+    redo_split(s.jlo, kSrcVecs, [&](int i, int e, float v) { aux[4 * tid + 1024 * i + e] = v; });
+    tk.mark(1);
+    if (k + 1 < kChunks) {                          // the next chunk's rows travel under this chunk's interpolation
+      nxt = span_of(k + 1, (k + 2 < kChunks) ? kChunkRows : kImageRows - kChunkRows * (k + 1));
+      fetch(X, NZ, nxt.jlo, std::integral_constant<int, kSrcVecs>{});
+    }
+    __syncthreads();
+    tk.mark(2);
+    const int first = cur0 + 256 * kChunkRows * k + tid;
+#pragma unroll
+    for (int u = 0; u < out_rows; ++u) {
+      const int cu = first + 256 * u;
+      const int cc = min(max(cu, s.lo), s.hi);      // keeps j inside the chunk; positions outside [0, L1) are 0 below
+      const double pos = fmin(mul_rn((double)cc, step), dlast);
+      const int j = (int)pos;
+      const double fr = pos - (double)j;
+      const float s0 = aux[j - s.jlo], s1 = aux[j - s.jlo + 1];   // (at j == last the fraction is 0, s1 unused)
+      const float mid = (float)add_rn(mul_rn(sub_rn((double)s1, (double)s0), fr), (double)s0);
+      float v = (fr == 0.0) ? s0 : mid;
+      v = ((unsigned)cu < (unsigned)L1) ? v : 0.f;  // outside: the zero fill of the shift / beyond the signal
+      image(kChunkRows * k + u, mul_rn(v, gain));
+    }
+    __syncthreads();                                // the area is rewritten by the next chunk, then by the twiddles
+    tk.mark(3);
+    tk.batch();
+  }
+  return true;
+}
+
 // Stages the augmented padded signal of one workgroup into the LDS image.
-__device__ __forceinline__ void stage_augmented(const Chain& c, float* __restrict__ lds, int p0, int n,
-                                       int len, int tid, unsigned long long* st = nullptr) {
+// (Kernel 1's first twiddles are requested AFTER this: issued behind the first fetch instead, they cost
+// 32 registers through the staging -- spills at the 256-register limit -- and measured 0.853 against 0.831 ms.)
+__device__ __forceinline__ void stage_augmented(const Chain& c, float* __restrict__ lds, float* __restrict__ aux, int p0,
+                                                int n, int len, int tid, int tune, unsigned long long* st = nullptr) {
   Ticker tk;
   tk.start();
   auto report = [&]() {
@@ -748,6 +964,7 @@ __device__ __forceinline__ void stage_augmented(const Chain& c, float* __restric
       st[9] = tk.acc[1];
       st[10] = tk.acc[2];
       st[11] = tk.batches;
+      st[12] = tk.acc[3];
     }
 #endif
   };
@@ -761,6 +978,15 @@ __device__ __forceinline__ void stage_augmented(const Chain& c, float* __restric
   {
     const Shipped f = match_shipped(c);
     if (f.ok) {
+      const bool sp = c.speed_at >= 0, nz = f.noise_k >= 0;
+      const bool done = (tune & 1) ? false : sp ? (nz ? stage_contiguous<true, true>(c, f, lds, aux, p0, len, tid, tk)
+                                 : stage_contiguous<true, false>(c, f, lds, aux, p0, len, tid, tk))
+                           : (nz ? stage_contiguous<false, true>(c, f, lds, aux, p0, len, tid, tk)
+                                 : stage_contiguous<false, false>(c, f, lds, aux, p0, len, tid, tk));
+      if (done) {
+        report();
+        return;
+      }
       if (c.speed_at >= 0) {
         if (f.noise_k >= 0) stage_shipped<true, true, 14>(c, f, lds, p0, n, len, tid, tk);
         else stage_shipped<true, false, 21>(c, f, lds, p0, n, len, tid, tk);
@@ -850,7 +1076,8 @@ __device__ __forceinline__ void stage_augmented(const Chain& c, float* __restric
 template <int NMT, bool POWER, bool AUG, int BANK>
 __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   // waveform image | twiddle slots, reused as the output tile after the k-loop
-  constexpr int kAuxFloats = (16 * NMT * kTileStride > 2 * kDftStepFloats) ? 16 * NMT * kTileStride : 2 * kDftStepFloats;
+  constexpr int kAuxTile = (16 * NMT * kTileStride > 2 * kDftStepFloats) ? 16 * NMT * kTileStride : 2 * kDftStepFloats;
+  constexpr int kAuxFloats = (AUG && kAuxTile < kStageAuxFloats) ? kStageAuxFloats : kAuxTile;   // (AUG: stage_contiguous)
   __shared__ __attribute__((aligned(16))) float lds[kLdsWaveFloats + kAuxFloats];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -860,6 +1087,9 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   const int n = a.n_samples;
   const int T = a.n_frames;
   const int nblk = (T + kBlockFrames - 1) / kBlockFrames;   // == gridDim.x, without the late kernarg load
+  // AUG: the staging outranks the partner workgroup's MFMA stream in the SIMD's arbiter (-1.7 % on the
+  // augmented kernel; without augmentation the staging is short and the same switch costs 1.4 %)
+  if (AUG) __builtin_amdgcn_s_setprio(3);
   const Source src = make_source(a, b);
   const float* __restrict__ w = src.w;
   int raw_len = a.lengths[b];
@@ -953,10 +1183,10 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
                             ((reinterpret_cast<uintptr_t>(src.pcm + i_first) & 15u) == 0);
     if (AUG) {
 #ifdef WFE_STAMPS
-      stage_augmented(c, lds, p0, n, len, tid,
+      stage_augmented(c, lds, lds + kLdsWaveFloats, p0, n, len, tid, a.tune,
                                   (a.stamps && lane == 0) ? a.stamps + ((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + blockIdx.x) * 4 + wave) * kStampRow : nullptr);
 #else
-      stage_augmented(c, lds, p0, n, len, tid);
+      stage_augmented(c, lds, lds + kLdsWaveFloats, p0, n, len, tid, a.tune);
 #endif
     } else if (interior16) {
       // 16-bit PCM: 8 samples per 16-byte load, converted on the way into LDS
@@ -1040,6 +1270,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   __syncthreads();
   WFE_STAMP(2);
 
+  if (AUG) __builtin_amdgcn_s_setprio(0);
   // ---- folded DFT as 4 GEMMs on v_mfma_f32_16x16x4_f32
   const int jl = lane & 15;
   const int kk = lane >> 4;
@@ -1658,7 +1889,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const FrontArgs a, const d
 __global__ __launch_bounds__(256) void waveform_kernel(const FrontArgs a, float* __restrict__ out,
                                                        int* __restrict__ out_len) {
   constexpr int kSpan = kBlockFrames * kHop;            // output samples per workgroup (10240)
-  __shared__ __attribute__((aligned(16))) float lds[kLdsWaveFloats];
+  __shared__ __attribute__((aligned(16))) float lds[kLdsWaveFloats + kStageAuxFloats];
   const int b = blockIdx.y;
   const Source src = make_source(a, b);
   int raw_len = a.lengths[b];
@@ -1670,7 +1901,7 @@ __global__ __launch_bounds__(256) void waveform_kernel(const FrontArgs a, float*
   const int keep = L < a.n_samples ? L : a.n_samples;
   if (blockIdx.x == 0 && threadIdx.x == 0 && out_len) out_len[b] = L;
   const int p0 = blockIdx.x * kSpan;                    // staging position q holds sample p0 + q - 200
-  stage_augmented(c, lds, p0, a.n_samples, keep, threadIdx.x);
+  stage_augmented(c, lds, lds + kLdsWaveFloats, p0, a.n_samples, keep, threadIdx.x, a.tune);
   __syncthreads();
   float* o = out + (long long)b * a.n_samples;
   for (int q = kHalf + threadIdx.x; q < kHalf + kSpan; q += 256) {
@@ -1864,7 +2095,8 @@ __global__ __launch_bounds__(256) void reverb_scale_kernel(const ReverbArgs a) {
 template <int NMT, bool POWER, bool AUG, int BANK>
 static hipError_t launch_k1(const FrontArgs& a, int batch, hipStream_t stream) {
   const dim3 grid((a.n_frames + kBlockFrames - 1) / kBlockFrames, batch);
-  hipLaunchKernelGGL((frontend_kernel<NMT, POWER, AUG, BANK>), grid, dim3(256), 0, stream, a);
+  // (WFE_TUNE & 8, diagnostic: 36 KB of unused dynamic LDS leave room for ONE workgroup per CU -- phases without a partner)
+  hipLaunchKernelGGL((frontend_kernel<NMT, POWER, AUG, BANK>), grid, dim3(256), (a.tune & 8) ? 36 * 1024 : 0, stream, a);
   return hipGetLastError();
 }
 
