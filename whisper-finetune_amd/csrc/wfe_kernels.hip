@@ -1087,8 +1087,9 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   const int n = a.n_samples;
   const int T = a.n_frames;
   const int nblk = (T + kBlockFrames - 1) / kBlockFrames;   // == gridDim.x, without the late kernarg load
-  // AUG: the staging outranks the partner workgroup's MFMA stream in the SIMD's arbiter (-1.7 % on the
-  // augmented kernel; without augmentation the staging is short and the same switch costs 1.4 %)
+  // AUG: the staging outranks the partner workgroup's MFMA stream in the SIMD's arbiter (-1.4 % on the
+  // augmented kernel; the k-loop at priority 2 or 3 instead, or both at 0, measured the same or worse;
+  // without augmentation the staging is short and the switch costs 1.4 %)
   if (AUG) __builtin_amdgcn_s_setprio(3);
   const Source src = make_source(a, b);
   const float* __restrict__ w = src.w;
