@@ -39,6 +39,7 @@ struct wfe_context {
   size_t ev_used = 0;
   unsigned* d_peaks = nullptr;              // reverb: max|x|, max|y| per utterance of a slice
   double* d_partials = nullptr;             // resolve pass: per-part sums of the batch slice
+  unsigned* d_tickets = nullptr;            // resolve pass: one arrival counter per utterance of the slice, zero between launches
   struct RsTable {
     float* d = nullptr;
     int L = 0, M = 0, taps = 0, k0 = 0;
@@ -166,6 +167,10 @@ int ensure_aug_workspace(wfe_context* h, size_t total_ops, const float* noise, c
   }
   if (!h->d_partials)
     HIP_TRY(h, hipMalloc(&h->d_partials, sizeof(double) * 2 * wfe::kResolveParts * kMaxBatchPerLaunch));
+  if (!h->d_tickets) {
+    HIP_TRY(h, hipMalloc(&h->d_tickets, sizeof(unsigned) * kMaxBatchPerLaunch));
+    HIP_TRY(h, hipMemsetAsync(h->d_tickets, 0, sizeof(unsigned) * kMaxBatchPerLaunch, stream));
+  }
   if (!h->d_heads) HIP_TRY(h, hipMalloc(&h->d_heads, sizeof(wfe::ChainHead) * kMaxBatchPerLaunch));
   if (n_noise > 0) {
     if ((size_t)n_noise > h->noise_cap) {
@@ -238,7 +243,7 @@ int run_frontend(wfe_context* h, const void* wav, int channels, const int64_t* o
       a.resolved = h->d_resolved;
       a.cops = h->d_cops;
       a.heads = h->d_heads;
-      HIP_TRY(h, wfe::launch_resolve(a, s.count, h->d_partials, stream));
+      HIP_TRY(h, wfe::launch_resolve(a, s.count, h->d_partials, h->d_tickets, stream));
     }
     hipEvent_t* ev = nullptr;
     if (h->timing && h->ev_used / 3 < kMaxTimedLaunches) {   // (beyond the cap launches go untimed)
@@ -317,6 +322,8 @@ int wfe_create(const wfe_config* cfg, wfe_handle* out) {
   if (e == hipSuccess) e = hipMalloc(&h->d_cops, kInitOps * wfe::kCopBytes);
   if (e == hipSuccess) h->resolved_cap = kInitOps;
   if (e == hipSuccess) e = hipMalloc(&h->d_partials, sizeof(double) * 2 * wfe::kResolveParts * kMaxBatchPerLaunch);
+  if (e == hipSuccess) e = hipMalloc(&h->d_tickets, sizeof(unsigned) * kMaxBatchPerLaunch);
+  if (e == hipSuccess) e = hipMemset(h->d_tickets, 0, sizeof(unsigned) * kMaxBatchPerLaunch);
   if (e == hipSuccess) e = hipMalloc(&h->d_heads, sizeof(wfe::ChainHead) * kMaxBatchPerLaunch);
   if (e == hipSuccess) e = hipMalloc(&h->d_noise_meansq, kInitNoise * wfe::kNoiseParts * sizeof(double));
   if (e == hipSuccess) h->noise_cap = kInitNoise;
@@ -352,6 +359,7 @@ int wfe_destroy(wfe_handle h) {
   for (auto& kv : h->rs_tables)
     if (kv.second.d) (void)hipFree(kv.second.d);
   if (h->d_partials) (void)hipFree(h->d_partials);
+  if (h->d_tickets) (void)hipFree(h->d_tickets);
   if (h->d_peaks) (void)hipFree(h->d_peaks);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   delete h;
@@ -501,7 +509,7 @@ int wfe_augment_waveform(wfe_handle h, const float* wav, const int64_t* offsets,
     a.resolved = h->d_resolved;
       a.cops = h->d_cops;
       a.heads = h->d_heads;
-    HIP_TRY(h, wfe::launch_resolve(a, s.count, h->d_partials, stream));
+    HIP_TRY(h, wfe::launch_resolve(a, s.count, h->d_partials, h->d_tickets, stream));
     HIP_TRY(h, wfe::launch_waveform(a, s.count, out + (long long)s.begin * n_samples,
                                     out_lengths ? out_lengths + s.begin : nullptr, stream));
   }

@@ -68,9 +68,10 @@ constexpr int kNoiseParts = 16;
 hipError_t launch_noise_meansq(const float* noise, const long long* noise_off, int n_noise, double* meansq,
                                hipStream_t stream);
 // resolve the data-dependent scalars of every utterance's chain (NOISE gains, AFFINE stats)
-// partials: workspace of batch x kResolveParts x 2 doubles
+// partials: workspace of batch x kResolveParts x 2 doubles; tickets: batch counters, zero before the FIRST
+// launch (every launch leaves them zero again)
 constexpr int kResolveParts = 16;
-hipError_t launch_resolve(const FrontArgs& a, int batch, double* partials, hipStream_t stream);
+hipError_t launch_resolve(const FrontArgs& a, int batch, double* partials, unsigned* tickets, hipStream_t stream);
 // augmented + padded waveform (batch, n_samples) and final lengths
 hipError_t launch_waveform(const FrontArgs& a, int batch, float* out, int* out_lengths, hipStream_t stream);
 

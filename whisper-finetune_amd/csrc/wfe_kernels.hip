@@ -1757,7 +1757,10 @@ __device__ inline int first_resolvable(const Chain& c) {
   return -1;
 }
 
-__global__ __launch_bounds__(256) void resolve_partial_kernel(const FrontArgs a, double* __restrict__ partials) {
+__device__ void resolve_utterance(const FrontArgs& a, const double* partials, int b, double* sh);
+
+__global__ __launch_bounds__(256) void resolve_partial_kernel(const FrontArgs a, double* partials,
+                                                              unsigned* __restrict__ tickets) {
   __shared__ double sh[4];
   const int b = blockIdx.y, part = blockIdx.x;
   const Source src = make_source(a, b);
@@ -1765,20 +1768,54 @@ __global__ __launch_bounds__(256) void resolve_partial_kernel(const FrontArgs a,
   if (raw_len < 0) raw_len = 0;
   const Chain c = make_chain(a, b, src, raw_len);
   const int k0 = first_resolvable(c);
-  if (k0 < 0) return;
   __shared__ COp cops[kMaxCops];
+  __shared__ int is_last;
   Chain cc = c;
-  {
+  if (k0 >= 0) {
     const bool compiled = compile_chain(c, cops, k0, (int)threadIdx.x);
     __syncthreads();
     if (compiled) cc.cops = cops;
   }
-  int L = chain_len(c, k0);
-  if (c.ops[k0].kind == WFE_AUG_AFFINE && L > a.n_samples) L = a.n_samples;
+  int L = k0 >= 0 ? chain_len(c, k0) : 0;
+  if (k0 >= 0 && c.ops[k0].kind == WFE_AUG_AFFINE && L > a.n_samples) L = a.n_samples;
   const int per = (L + kResolveParts - 1) / kResolveParts;
   const int lo = part * per, hi = (lo + per < L) ? lo + per : L;
   double s1 = 0.0, s2 = 0.0;
-  if (cc.cops && (c.speed_at < 0 || c.speed_at >= k0)) {
+  if (k0 == 0 && src.w && ((reinterpret_cast<uintptr_t>(src.w) & 15u) == 0)) {
+    // the signal entering the chain's first op is the source itself (the shipped order starts with NOISE):
+    // 16-byte loads, four rows in flight per thread
+    const f32x4* __restrict__ w4 = reinterpret_cast<const f32x4*>(src.w);
+    const int lo4 = (lo + 3) >> 2, hi4 = hi >> 2;                 // whole float4s inside [lo, hi)
+    auto take = [&](float x) {
+      s1 += (double)x;
+      s2 += (double)mul_rn(x, x);                                 // float32 squares, as sample ** 2
+    };
+    if (lo4 >= hi4) {
+      for (int i = lo + (int)threadIdx.x; i < hi; i += 256) take(src.w[i]);
+    } else {
+      if ((int)threadIdx.x < 4 * lo4 - lo) take(src.w[lo + threadIdx.x]);            // ragged head (< 4 samples)
+      if ((int)threadIdx.x < hi - 4 * hi4) take(src.w[4 * hi4 + threadIdx.x]);       // ragged tail
+      int i = lo4 + (int)threadIdx.x;
+      for (; i + 768 < hi4; i += 1024) {
+        const f32x4 v0 = w4[i], v1 = w4[i + 256], v2 = w4[i + 512], v3 = w4[i + 768];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) take(v0[e]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) take(v1[e]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) take(v2[e]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) take(v3[e]);
+      }
+      for (; i < hi4; i += 256) {
+        const f32x4 v = w4[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) take(v[e]);
+      }
+    }
+  } else if (k0 < 0) {
+    // nothing to sum: the chain has no data-dependent op
+  } else if (cc.cops && (c.speed_at < 0 || c.speed_at >= k0)) {
     constexpr int U = 8;
     const int S = seg_shift_sum(cc, 0, k0);
     for (int i0 = lo + (int)threadIdx.x; i0 < hi; i0 += 256 * U) {
@@ -1805,20 +1842,30 @@ __global__ __launch_bounds__(256) void resolve_partial_kernel(const FrontArgs a,
   s1 = block_sum<256>(s1, sh);
   s2 = block_sum<256>(s2, sh);
   if (threadIdx.x == 0) {
-    partials[((long long)b * kResolveParts + part) * 2 + 0] = s1;
-    partials[((long long)b * kResolveParts + part) * 2 + 1] = s2;
+    // The last of the utterance's kResolveParts workgroups to get here resolves the chain (what a second
+    // launch did in round 1: 0.020 ms + a launch gap per call).  The partial sums and the ticket are
+    // device-scope atomics (performed at the memory side, past the per-XCD L2s, no cache maintenance: a
+    // __threadfence() pair per workgroup -- an L2 write-back and invalidate each -- cost 0.58 ms per call);
+    // the sums have left the wave before the ticket is taken.
+    __hip_atomic_store(&partials[((long long)b * kResolveParts + part) * 2 + 0], s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&partials[((long long)b * kResolveParts + part) * 2 + 1], s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(&tickets[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (t == (unsigned)kResolveParts - 1u);
+    if (is_last) __hip_atomic_store(&tickets[b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next call
   }
+  __syncthreads();
+  if (!is_last) return;
+  resolve_utterance(a, partials, b, sh);
 }
 
-// One workgroup per utterance: walks its chain in order and fills the
-// data-dependent scalars of NOISE (gains, utils/reader.py:325-331) and AFFINE
+// One workgroup per utterance (the last of resolve_partial_kernel's to arrive): walks its chain in order
+// and fills the data-dependent scalars of NOISE (gains, utils/reader.py:325-331) and AFFINE
 // (mean / std, HF:172-191) ops.  An op's statistics are taken over the signal
 // ENTERING it, so earlier ops -- including earlier resolved ones -- are applied.
 // The first such op takes its sums from resolve_partial_kernel; any later one is
 // summed here.
-__global__ __launch_bounds__(256) void resolve_kernel(const FrontArgs a, const double* __restrict__ partials) {
-  __shared__ double sh[4];
-  const int b = blockIdx.x;
+__device__ void resolve_utterance(const FrontArgs& a, const double* partials, int b, double* sh) {
   const Source src = make_source(a, b);
   int raw_len = a.lengths[b];
   if (raw_len < 0) raw_len = 0;
@@ -1833,8 +1880,8 @@ __global__ __launch_bounds__(256) void resolve_kernel(const FrontArgs a, const d
     double s1 = 0.0, s2 = 0.0;
     if (first) {
       for (int p = 0; p < kResolveParts; ++p) {
-        s1 += partials[((long long)b * kResolveParts + p) * 2 + 0];
-        s2 += partials[((long long)b * kResolveParts + p) * 2 + 1];
+        s1 += __hip_atomic_load(&partials[((long long)b * kResolveParts + p) * 2 + 0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s2 += __hip_atomic_load(&partials[((long long)b * kResolveParts + p) * 2 + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     } else {
       for (int i = threadIdx.x; i < L; i += 256) {
@@ -1866,7 +1913,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(const FrontArgs a, const d
       }
       res[k] = r;
     }
-    __threadfence();
+    __threadfence_block();                    // (read back below by this workgroup only: later ops, make_cop)
     __syncthreads();
   }
   // the chain, compiled with its resolved scalars, for kernel 1 (load_chain)
@@ -2129,11 +2176,8 @@ hipError_t launch_noise_meansq(const float* noise, const long long* off, int n_n
   return hipGetLastError();
 }
 
-hipError_t launch_resolve(const FrontArgs& a, int batch, double* partials, hipStream_t stream) {
-  hipLaunchKernelGGL(resolve_partial_kernel, dim3(kResolveParts, batch), dim3(256), 0, stream, a, partials);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(resolve_kernel, dim3(batch), dim3(256), 0, stream, a, partials);
+hipError_t launch_resolve(const FrontArgs& a, int batch, double* partials, unsigned* tickets, hipStream_t stream) {
+  hipLaunchKernelGGL(resolve_partial_kernel, dim3(kResolveParts, batch), dim3(256), 0, stream, a, partials, tickets);
   return hipGetLastError();
 }
 
