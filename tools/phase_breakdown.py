@@ -62,7 +62,7 @@ print(f"{'total':22s} median {np.median(tot):9.0f}  p10 {np.percentile(tot, 10):
 if os.environ.get("WFE_PHASE_AUG") == "1":           # slots 8..11 carry the staging passes of SPEED chains
     t0, t1, t2, nb, t3 = s[:, 8], s[:, 9], s[:, 10], s[:, 11], s[:, 12]
     print("(WFE_TUNE & 1: gather form -- indices / gathers / arithmetic; else contiguous form of SPEED tiles -- "
-          "set-up + first fetch issue / wait + mix + LDS / next fetch issue + barrier / interpolation + barrier)")
+          "set-up / fetches' wait + mix + LDS / next fetch issue + barrier / interpolation + barrier)")
     for nme, sel in (("tiles staged in >= 3 batches (SPEED)", nb >= 3), ("tiles staged in 2 batches", nb == 2), ("tiles staged in 1 batch", nb == 1)):
         if not sel.any():
             continue

@@ -908,8 +908,8 @@ __device__ __forceinline__ bool stage_contiguous(const Chain& c, const Shipped f
   };
   constexpr int kChunks = (kImageRows + kChunkRows - 1) / kChunkRows;       // 3
   Span nxt = span_of(0, kChunkRows);
-  fetch(X, NZ, nxt.jlo, std::integral_constant<int, kSrcVecs>{});
   tk.mark(0);
+  fetch(X, NZ, nxt.jlo, std::integral_constant<int, kSrcVecs>{});
 #pragma unroll
   for (int k = 0; k < kChunks; ++k) {
     const Span s = nxt;
@@ -930,18 +930,30 @@ __device__ __forceinline__ bool stage_contiguous(const Chain& c, const Shipped f
     __syncthreads();
     tk.mark(2);
     const int first = cur0 + 256 * kChunkRows * k + tid;
-#pragma unroll
-    for (int u = 0; u < out_rows; ++u) {
-      const int cu = first + 256 * u;
-      const int cc = min(max(cu, s.lo), s.hi);      // keeps j inside the chunk; positions outside [0, L1) are 0 below
-      const double pos = fmin(mul_rn((double)cc, step), dlast);
+    // a chunk whose positions all lie inside [0, L1) -- nearly every one -- needs neither the clamp of the
+    // position nor the zero fill, and counts its positions in float64 directly
+    const bool inside = uni((int)(cur0 + 256 * kChunkRows * k >= 0 && cur0 + 256 * (kChunkRows * k + out_rows) - 1 < L1));
+    auto interpolate = [&](double pos, int u) {
       const int j = (int)pos;
-      const double fr = pos - (double)j;
+      const double fr = __builtin_amdgcn_fract(pos);              // pos - floor(pos), exact; pos >= 0
       const float s0 = aux[j - s.jlo], s1 = aux[j - s.jlo + 1];   // (at j == last the fraction is 0, s1 unused)
       const float mid = (float)add_rn(mul_rn(sub_rn((double)s1, (double)s0), fr), (double)s0);
-      float v = (fr == 0.0) ? s0 : mid;
-      v = ((unsigned)cu < (unsigned)L1) ? v : 0.f;  // outside: the zero fill of the shift / beyond the signal
-      image(kChunkRows * k + u, mul_rn(v, gain));
+      return (fr == 0.0) ? s0 : mid;
+    };
+    if (inside) {
+      const double dfirst = (double)first;
+#pragma unroll
+      for (int u = 0; u < out_rows; ++u)
+        image(kChunkRows * k + u, mul_rn(interpolate(fmin(mul_rn(dfirst + (double)(256 * u), step), dlast), u), gain));
+    } else {
+#pragma unroll
+      for (int u = 0; u < out_rows; ++u) {
+        const int cu = first + 256 * u;
+        const int cc = min(max(cu, s.lo), s.hi);    // keeps j inside the chunk; positions outside [0, L1) are 0 below
+        float v = interpolate(fmin(mul_rn((double)cc, step), dlast), u);
+        v = ((unsigned)cu < (unsigned)L1) ? v : 0.f;  // outside: the zero fill of the shift / beyond the signal
+        image(kChunkRows * k + u, mul_rn(v, gain));
+      }
     }
     __syncthreads();                                // the area is rewritten by the next chunk, then by the twiddles
     tk.mark(3);
