@@ -3,10 +3,14 @@ golden outputs of the reference's CustomDataset (utils/reader.py:246-340) and
 against the CPU oracle.
 
 Bar: speed / shift / volume are index and single-rounding float32 work ->
-BIT-EXACT.  Noise mixing depends on two RMS reductions whose float32 summation
-order numpy fixes and the GPU does not reproduce (it reduces in float64): the
-gains may differ in the last ulp, so the mixed waveform is compared with
-|err| <= 2e-6 * max|x| (about 4 ulp at full scale), stated here."""
+BIT-EXACT.  Noise mixing depends on two gains that the reference computes through
+10 * np.log10(np.mean(x ** 2)) and 10. ** (g / 20.) on float32 scalars.  NumPy's
+float32 log10 / power are not correctly rounded and depend on the host (SVML on
+AVX-512, libm elsewhere; tools/numpy_log10_check.py: 52 % / 21 % of arguments off by
+1-2 ulp on the build container), so the reference's own gains vary in the last 2-4
+ulp between hosts; the GPU sums in float64 and lands inside that spread.  The mixed
+waveform is therefore compared with |err| <= 2e-6 * max|x| (about 4 ulp at full
+scale), stated here."""
 import json
 import random
 

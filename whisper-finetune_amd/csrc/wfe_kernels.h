@@ -17,7 +17,7 @@ struct Resolved {
 
 constexpr int kTileStats = 12;   // floats kernel 1 leaves per 64-frame tile for kernel 2
 
-// What resolve_kernel leaves per utterance for kernel 1: the chain's geometry, and (in `cops`)
+// What the resolve pass (resolve_utterance) leaves per utterance for kernel 1: the chain's geometry, and (in `cops`)
 // its ops compiled with their resolved scalars -- kernel 1 then needs two load round trips to
 // set a chain up instead of walking the op list (five dependent ones).
 struct ChainHead {
@@ -52,8 +52,8 @@ struct FrontArgs {
   const long long* noise_off;
   const double* noise_meansq;    // (n_noise x kNoiseParts) partial sums of squares of each noise clip
   Resolved* resolved;            // (total ops) filled by the reduce kernel
-  void* cops;                    // (total ops x kCopBytes) compiled ops, written by resolve_kernel
-  ChainHead* heads;              // (batch) written by resolve_kernel
+  void* cops;                    // (total ops x kCopBytes) compiled ops, written by the resolve pass
+  ChainHead* heads;              // (batch) written by the resolve pass
   unsigned long long* stamps;    // diagnostic builds (-DWFE_STAMPS) only: 16 clock stamps per wave
   int tune;                      // experiment switches (WFE_TUNE, read at wfe_create); 0 in production
 };

@@ -28,7 +28,7 @@
 // float16 / bfloat16 output).
 //
 // Augmentation (AUG builds): see stage_shipped / seg_apply; data-dependent gains are
-// resolved beforehand by resolve_partial_kernel + resolve_kernel, which also leaves the
+// resolved beforehand by resolve_partial_kernel (its last workgroup per utterance), which also leaves the
 // chain compiled for kernel 1 (load_chain).
 //
 // Numerics: f32 MFMA is a k-ordered fmaf chain (exact f32).  Tables are built in
@@ -380,7 +380,7 @@ __device__ inline bool compile_chain(const Chain& c, COp* cops, int n_use, int t
   if (tid < n_use) cops[tid] = make_cop(c, tid);
   return true;
 }
-// Kernel 1's set-up: the chain as resolve_kernel compiled it (head + ops -> LDS).  Two load
+// Kernel 1's set-up: the chain as resolve_utterance compiled it (head + ops -> LDS).  Two load
 // round trips (head / offsets, then the ops); the caller synchronises the workgroup.
 __device__ __forceinline__ Chain load_chain(const FrontArgs& a, int b, const Source& src, int raw_len, COp* cops_lds,
                                             int tid) {
@@ -1761,7 +1761,7 @@ __device__ inline float rms_db_f32(double meansq) { return mul_rn(10.0f, log10f(
 // Statistics of the signal ENTERING the first NOISE / AFFINE op of every utterance
 // (the only one in the reference's configurations), kResolveParts workgroups per
 // utterance so that the pass runs at HBM rate: float64 partial sums of x and x*x
-// over a fixed partition, combined in a fixed order by resolve_kernel (the result
+// over a fixed partition, combined in a fixed order by resolve_utterance (the result
 // does not depend on scheduling).
 __device__ inline int first_resolvable(const Chain& c) {
   for (int k = 0; k < c.n_ops; ++k)
