@@ -343,6 +343,49 @@ def test_contiguous_staging_matches_gather_form(fe, monkeypatch):
         assert not wav[i, kk:].any()
 
 
+def test_full_batch_augment_properties(fe):
+    """BASELINE config 3 size (batch 256 x 30 s, noise -> speed -> shift -> volume drawn as bench.py --augment
+    draws them): size-independent properties.  (1) Every row of the batch equals the same utterance and plan
+    run in a batch of 8 (bits: the gains come from fixed-partition sums, so they do not depend on the batch).
+    (2) The fused launch equals the log-mel of the augmented waveform that waveform_kernel materialises
+    (bits: the same staging code feeds both).  (3) Reversing the batch reverses the output.  (4) Two rows
+    against the CPU oracle."""
+    from wfe_amd.augment import AugmentPlanner
+    from wfe_amd.frontend import NoiseBank
+    cfg = [
+        {"type": "noise", "params": {"min_snr_dB": 10, "max_snr_dB": 50}, "prob": 1.0},
+        {"type": "speed", "params": {"min_speed_rate": 0.9, "max_speed_rate": 1.1, "num_rates": 3}, "prob": 1.0},
+        {"type": "shift", "params": {"min_shift_ms": -5, "max_shift_ms": 5}, "prob": 1.0},
+        {"type": "volume", "params": {"min_gain_dBFS": -15, "max_gain_dBFS": 15}, "prob": 1.0},
+    ]
+    B, K = 256, 8
+    bank = [cases.noise_clip(j, 10.0) for j in range(4)]
+    planner = AugmentPlanner(cfg, [len(b) for b in bank])
+    base = np.stack([cases.bench_clip(40 + s) for s in range(K)])
+    plans8 = [planner.draw(480000, 16000, random.Random(900 + s))[0] for s in range(K)]
+    idx = np.arange(B) % K
+    dense = torch.from_numpy(base[idx]).to(fe.device)
+    lens = torch.full((B,), 480000, dtype=torch.int32, device=fe.device)
+    nb = NoiseBank(bank, fe.device)
+    plans = [plans8[i] for i in idx]
+    out = fe.augment_logmel(dense, lens, plans, nb)
+    solo = fe.augment_logmel(dense[:K], lens[:K], plans8, nb)
+    rev = fe.augment_logmel(dense.flip(0), lens, plans[::-1], nb)
+    wav, wl = fe.augment_waveform(dense[:K], lens[:K], plans8, nb, n_samples=480000)
+    staged = fe.logmel(wav, torch.clamp(wl, max=480000).to(torch.int32))
+    torch.cuda.synchronize()
+    assert torch.equal(out, solo[torch.from_numpy(idx).to(fe.device)])
+    assert torch.equal(rev.flip(0), out)
+    assert torch.equal(staged, solo)
+    want = []
+    for s in range(2):
+        aug, _, _ = oa.augment(base[s].copy(), 16000, cfg, random.Random(900 + s), bank)
+        want.append(aug)
+    ref = ol.logmel_f32(want, n_mel=80)
+    err = np.abs(solo[:2].cpu().numpy() - ref).max()
+    assert err <= 1e-4, err
+
+
 def _rir(seed, n):
     """A synthetic room impulse response: direct path + exponentially decaying noise."""
     rng = np.random.default_rng(seed)
