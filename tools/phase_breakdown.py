@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "whisper-finetune_amd"))
 from wfe_amd import _lib  # noqa: E402
 
-_lib.LIB_PATH = os.path.join(ROOT, "whisper-finetune_amd", "wfe_amd", os.environ.get("WFE_STAMP_LIB", "libwfe_hip_stamps.so"))
+_lib.LIB_PATH = os.path.join(ROOT, "tools", "build", os.environ.get("WFE_STAMP_LIB", "libwfe_hip_stamps.so"))
 from wfe_amd.frontend import HipFrontEnd  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
