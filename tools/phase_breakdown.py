@@ -67,7 +67,8 @@ if os.environ.get("WFE_PHASE_AUG") == "1":           # slots 8..11 carry the sta
         if not sel.any():
             continue
         print(f"{nme}: {sel.sum()} of {len(s)} waves; staging phase median {np.median(d[sel, 0]):.0f}")
-        for lab, v in (("part 0", t0), ("part 1", t1), ("part 2", t2), ("part 3", t3)):
+        pre, post = s[:, 13] - s[:, 0], s[:, 1] - s[:, 14]      # chain set-up before the staging; twiddle request + slot writes after
+        for lab, v in (("before (chain load)", pre), ("part 0", t0), ("part 1", t1), ("part 2", t2), ("part 3", t3), ("after (twiddles)", post)):
             print(f"  {lab:26s} median {np.median(v[sel]):9.0f}  p10 {np.percentile(v[sel], 10):9.0f}  p90 {np.percentile(v[sel], 90):9.0f}")
     sys.exit(0)
 

@@ -23,6 +23,17 @@ constexpr int kTileStats = 12;   // floats kernel 1 leaves per 64-frame tile for
 struct ChainHead {
   int n_ops, speed_at, len1, compiled;   // compiled: cops hold the chain (n_ops <= 16)
   double step;
+  // The chain shape the reference's own configuration draws ([NOISE]? [SPEED]? [SHIFT]? [VOLUME]?), matched
+  // once per utterance: everything kernel 1's contiguous staging needs, in one uniform 80-byte load instead
+  // of the op array copied through LDS behind a barrier (absent SHIFT / VOLUME are shift 0 / gain 1.0f).
+  int shipped;                           // 1: the fields below describe the whole chain
+  int noise_k;                           // index of the NOISE op or -1
+  int shift;
+  float gain;
+  int noise_len, noise_start;            // the NOISE op's clip: length, start of the slice when longer than the utterance
+  long long noise_o0;                    // its offset in the bank
+  float ra, rb;                          // resolved gains
+  double noise_inv;                      // 1 / noise_len
 };
 constexpr int kCopBytes = 48;            // sizeof(COp), wfe_kernels.hip
 

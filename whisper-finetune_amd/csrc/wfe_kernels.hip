@@ -29,7 +29,7 @@
 //
 // Augmentation (AUG builds): see stage_shipped / seg_apply; data-dependent gains are
 // resolved beforehand by resolve_partial_kernel (its last workgroup per utterance), which also leaves the
-// chain compiled for kernel 1 (load_chain).
+// chain compiled for kernel 1 (chain_from_head / copy_cops).
 //
 // Numerics: f32 MFMA is a k-ordered fmaf chain (exact f32).  Tables are built in
 // float64 and rounded once.
@@ -380,11 +380,11 @@ __device__ inline bool compile_chain(const Chain& c, COp* cops, int n_use, int t
   if (tid < n_use) cops[tid] = make_cop(c, tid);
   return true;
 }
-// Kernel 1's set-up: the chain as resolve_utterance compiled it (head + ops -> LDS).  Two load
-// round trips (head / offsets, then the ops); the caller synchronises the workgroup.
-__device__ __forceinline__ Chain load_chain(const FrontArgs& a, int b, const Source& src, int raw_len, COp* cops_lds,
-                                            int tid) {
-  const ChainHead h = a.heads[b];
+// Kernel 1's set-up: the chain as resolve_utterance left it.  The head alone (one uniform load) serves the
+// contiguous staging; the gather forms also want the compiled ops in LDS (copy_cops: a second load round
+// trip and a barrier, paid only by the tiles that fall back).
+__device__ __forceinline__ Chain chain_from_head(const FrontArgs& a, const ChainHead& h, int b, const Source& src,
+                                                 int raw_len) {
   const int lo = a.op_begin[b];
   Chain c;
   c.ops = a.ops + lo;
@@ -397,9 +397,15 @@ __device__ __forceinline__ Chain load_chain(const FrontArgs& a, int b, const Sou
   c.step = h.step;
   c.noise = a.noise;
   c.noise_off = a.noise_off;
-  c.cops = h.compiled ? cops_lds : nullptr;
-  if (h.compiled && tid < h.n_ops) cops_lds[tid] = reinterpret_cast<const COp*>(a.cops)[lo + tid];
+  c.cops = nullptr;
   return c;
+}
+// (uniform: every thread of the workgroup calls it, or none)
+__device__ __forceinline__ void copy_cops(const FrontArgs& a, const ChainHead& h, int b, Chain& c, COp* cops_lds, int tid) {
+  if (!h.compiled) return;                    // more than kMaxCops ops: evaluated from global memory
+  if (tid < h.n_ops) cops_lds[tid] = reinterpret_cast<const COp*>(a.cops)[a.op_begin[b] + tid];
+  __syncthreads();
+  c.cops = cops_lds;
 }
 // (seg_shift_sum / seg_apply below require the compiled chain, c.cops != null)
 __device__ __forceinline__ COp get_cop(const Chain& c, int k) { return c.cops[k]; }
@@ -534,12 +540,13 @@ __device__ __forceinline__ double speed_pos(const Chain& c, int i) {
 // over the batches of one tile.  Empty in the shipped library.
 struct Ticker {
 #ifdef WFE_STAMPS
-  unsigned long long prev, acc[4];
+  unsigned long long prev, acc[4], t_start;
   int batches;
   __device__ __forceinline__ void start() {
     acc[0] = acc[1] = acc[2] = acc[3] = 0;
     batches = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(prev)::"memory");
+    t_start = prev;
   }
   __device__ __forceinline__ void tick(int k) {
     unsigned long long t_;
@@ -791,12 +798,11 @@ __device__ __forceinline__ int mod_clip(int s, int ln, double inv) {       // s 
 }
 
 template <bool SPEED, bool NOISE>
-__device__ __forceinline__ bool stage_contiguous(const Chain& c, const Shipped f, float* __restrict__ lds,
+__device__ __forceinline__ bool stage_contiguous(const Chain& c, const ChainHead& f, float* __restrict__ lds,
                                                  float* __restrict__ aux, int p0, int len, int tid, Ticker& tk) {
   const int L0 = c.len0, last = L0 - 1, L1 = SPEED ? c.len1 : L0;
   const int cur0 = p0 - kHalf + f.shift;          // position q is index cur0 + q of the chain's last segment
-  const COp nop = get_cop(c, NOISE ? f.noise_k : 0);
-  const int ln = NOISE ? uni(nop.ln) : 0, start = NOISE ? uni(nop.i1) : 0;
+  const int ln = NOISE ? f.noise_len : 0, start = NOISE ? f.noise_start : 0;
   const bool wrap = NOISE && ln < L0;
   const double step = c.step, dlast = (double)last;
   auto src_of = [&](int cu) { return (int)fmin(mul_rn((double)cu, step), dlast); };
@@ -812,9 +818,9 @@ __device__ __forceinline__ bool stage_contiguous(const Chain& c, const Shipped f
   }
   if (!uni((int)ok)) return false;
 
-  const float* __restrict__ clip = c.noise + (NOISE ? uni(nop.o0) : 0ll);
-  const float ra = nop.ra, rb = nop.rb, gain = f.gain;
-  const double inv = nop.inv;
+  const float* __restrict__ clip = c.noise + (NOISE ? f.noise_o0 : 0ll);
+  const float ra = f.ra, rb = f.rb, gain = f.gain;
+  const double inv = f.noise_inv;
   const int t16 = tid * 16;
   const unsigned ln4 = (unsigned)ln * 4u;
   // sample *= gain; noise *= gain; sample += noise: three float32 roundings (utils/reader.py:330-340)
@@ -962,11 +968,13 @@ __device__ __forceinline__ bool stage_contiguous(const Chain& c, const Shipped f
   return true;
 }
 
-// Stages the augmented padded signal of one workgroup into the LDS image.
+// Stages the augmented padded signal of one workgroup into the LDS image: the gather forms (every tile, every
+// chain); stage_from_head tries the contiguous form first.
 // (Kernel 1's first twiddles are requested AFTER this: issued behind the first fetch instead, they cost
 // 32 registers through the staging -- spills at the 256-register limit -- and measured 0.853 against 0.831 ms.)
-__device__ __forceinline__ void stage_augmented(const Chain& c, float* __restrict__ lds, float* __restrict__ aux, int p0,
-                                                int n, int len, int tid, int tune, unsigned long long* st = nullptr) {
+__device__ __forceinline__ void stage_augmented(const FrontArgs& a, const ChainHead& h, int b, Chain& c, COp* cops_lds,
+                                                float* __restrict__ lds, float* __restrict__ aux, int p0, int n, int len,
+                                                int tid, unsigned long long* st = nullptr) {
   Ticker tk;
   tk.start();
   auto report = [&]() {
@@ -977,9 +985,23 @@ __device__ __forceinline__ void stage_augmented(const Chain& c, float* __restric
       st[10] = tk.acc[2];
       st[11] = tk.batches;
       st[12] = tk.acc[3];
+      st[13] = tk.t_start;                      // absolute: entry of the staging, and its exit
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st[14])::"memory");
     }
 #endif
   };
+  if (h.shipped && !(a.tune & 1)) {             // (WFE_TUNE & 1: the gather forms everywhere, for A/B and the identity test)
+    const bool sp = h.speed_at >= 0, nz = h.noise_k >= 0;
+    const bool done = sp ? (nz ? stage_contiguous<true, true>(c, h, lds, aux, p0, len, tid, tk)
+                               : stage_contiguous<true, false>(c, h, lds, aux, p0, len, tid, tk))
+                         : (nz ? stage_contiguous<false, true>(c, h, lds, aux, p0, len, tid, tk)
+                               : stage_contiguous<false, false>(c, h, lds, aux, p0, len, tid, tk));
+    if (done) {
+      report();
+      return;
+    }
+  }
+  copy_cops(a, h, b, c, cops_lds, tid);
   if (!c.cops) {                                // more than kMaxCops ops: per-position evaluation from global memory
     for (int q = tid; q < kBlockSamples; q += 256) {
       const int i = padded_index(q, p0, n, len);
@@ -990,15 +1012,6 @@ __device__ __forceinline__ void stage_augmented(const Chain& c, float* __restric
   {
     const Shipped f = match_shipped(c);
     if (f.ok) {
-      const bool sp = c.speed_at >= 0, nz = f.noise_k >= 0;
-      const bool done = (tune & 1) ? false : sp ? (nz ? stage_contiguous<true, true>(c, f, lds, aux, p0, len, tid, tk)
-                                 : stage_contiguous<true, false>(c, f, lds, aux, p0, len, tid, tk))
-                           : (nz ? stage_contiguous<false, true>(c, f, lds, aux, p0, len, tid, tk)
-                                 : stage_contiguous<false, false>(c, f, lds, aux, p0, len, tid, tk));
-      if (done) {
-        report();
-        return;
-      }
       if (c.speed_at >= 0) {
         if (f.noise_k >= 0) stage_shipped<true, true, 14>(c, f, lds, p0, n, len, tid, tk);
         else stage_shipped<true, false, 21>(c, f, lds, p0, n, len, tid, tk);
@@ -1111,10 +1124,11 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   Chain c;
   int len = raw_len;
   __shared__ COp cops[AUG ? kMaxCops : 1];
+  ChainHead head;
   if (AUG) {
-    c = load_chain(a, b, src, raw_len, cops, tid);
+    head = a.heads[b];
+    c = chain_from_head(a, head, b, src, raw_len);
     len = chain_len(c, c.n_ops);
-    __syncthreads();
   }
   if (len > n) len = n;                         // truncation=True (HF:300-307)
   const int p0 = t0 * kHop;
@@ -1196,10 +1210,10 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
                             ((reinterpret_cast<uintptr_t>(src.pcm + i_first) & 15u) == 0);
     if (AUG) {
 #ifdef WFE_STAMPS
-      stage_augmented(c, lds, lds + kLdsWaveFloats, p0, n, len, tid, a.tune,
+      stage_augmented(a, head, b, c, cops, lds, lds + kLdsWaveFloats, p0, n, len, tid,
                                   (a.stamps && lane == 0) ? a.stamps + ((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + blockIdx.x) * 4 + wave) * kStampRow : nullptr);
 #else
-      stage_augmented(c, lds, lds + kLdsWaveFloats, p0, n, len, tid, a.tune);
+      stage_augmented(a, head, b, c, cops, lds, lds + kLdsWaveFloats, p0, n, len, tid);
 #endif
     } else if (interior16) {
       // 16-bit PCM: 8 samples per 16-byte load, converted on the way into LDS
@@ -1928,10 +1942,12 @@ __device__ void resolve_utterance(const FrontArgs& a, const double* partials, in
     __threadfence_block();                    // (read back below by this workgroup only: later ops, make_cop)
     __syncthreads();
   }
-  // the chain, compiled with its resolved scalars, for kernel 1 (load_chain)
+  // the chain, compiled with its resolved scalars, for kernel 1 (copy_cops)
   const bool fits = c.n_ops <= kMaxCops;
   if (fits && (int)threadIdx.x < c.n_ops)
     reinterpret_cast<COp*>(a.cops)[a.op_begin[b] + threadIdx.x] = make_cop(c, (int)threadIdx.x);
+  __threadfence_block();                      // (thread 0 reads the compiled ops back below)
+  __syncthreads();
   if (threadIdx.x == 0) {
     ChainHead h;
     h.n_ops = c.n_ops;
@@ -1939,6 +1955,35 @@ __device__ void resolve_utterance(const FrontArgs& a, const double* partials, in
     h.len1 = c.len1;
     h.compiled = fits ? 1 : 0;
     h.step = c.step;
+    h.shipped = 0;
+    h.noise_k = -1;
+    h.shift = 0;
+    h.gain = 1.0f;
+    h.noise_len = h.noise_start = 0;
+    h.noise_o0 = 0;
+    h.ra = 0.f;
+    h.rb = 1.f;
+    h.noise_inv = 0.0;
+    if (fits) {
+      Chain cc = c;
+      cc.cops = reinterpret_cast<const COp*>(a.cops) + a.op_begin[b];
+      const Shipped f = match_shipped(cc);
+      if (f.ok) {
+        h.shipped = 1;
+        h.noise_k = f.noise_k;
+        h.shift = f.shift;
+        h.gain = f.gain;
+        if (f.noise_k >= 0) {
+          const COp nop = get_cop(cc, f.noise_k);
+          h.noise_len = nop.ln;
+          h.noise_start = nop.i1;
+          h.noise_o0 = nop.o0;
+          h.ra = nop.ra;
+          h.rb = nop.rb;
+          h.noise_inv = nop.inv;
+        }
+      }
+    }
     a.heads[b] = h;
   }
 }
@@ -1955,13 +2000,13 @@ __global__ __launch_bounds__(256) void waveform_kernel(const FrontArgs a, float*
   int raw_len = a.lengths[b];
   if (raw_len < 0) raw_len = 0;
   __shared__ COp cops[kMaxCops];
-  Chain c = load_chain(a, b, src, raw_len, cops, (int)threadIdx.x);
-  __syncthreads();
+  const ChainHead head = a.heads[b];
+  Chain c = chain_from_head(a, head, b, src, raw_len);
   const int L = chain_len(c, c.n_ops);
   const int keep = L < a.n_samples ? L : a.n_samples;
   if (blockIdx.x == 0 && threadIdx.x == 0 && out_len) out_len[b] = L;
   const int p0 = blockIdx.x * kSpan;                    // staging position q holds sample p0 + q - 200
-  stage_augmented(c, lds, lds + kLdsWaveFloats, p0, a.n_samples, keep, threadIdx.x, a.tune);
+  stage_augmented(a, head, b, c, cops, lds, lds + kLdsWaveFloats, p0, a.n_samples, keep, threadIdx.x);
   __syncthreads();
   float* o = out + (long long)b * a.n_samples;
   for (int q = kHalf + threadIdx.x; q < kHalf + kSpan; q += 256) {
