@@ -614,6 +614,7 @@ int wfe_resample(wfe_handle h, const void* in, int32_t pcm_channels, const int64
     a.taps = t.taps;
     a.k0 = t.k0;
     a.out_per_block = (int)opb;
+    a.tune = h->tune;
     HIP_TRY(h, wfe::launch_resample(a, s.count, stream));
   }
   return WFE_OK;

@@ -102,6 +102,7 @@ struct ResampleArgs {
   const float* table;            // [taps][L] filter, wfe_build_resample_table
   int L, M, taps, k0;
   int out_per_block;             // outputs per workgroup: a multiple of 256, <= 2048, span fits kRsSpanFloats
+  int tune;                      // experiment switches (WFE_TUNE)
 };
 hipError_t launch_resample(const ResampleArgs& a, int batch, hipStream_t stream);
 

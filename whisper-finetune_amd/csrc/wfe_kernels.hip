@@ -2095,6 +2095,103 @@ __global__ __launch_bounds__(256) void resample_kernel(const ResampleArgs a) {
   }
 }
 
+// The same resampler with the outputs of a thread sharing ONE filter phase.  Outputs n and n + S have the same
+// phase when L divides S, and their input windows start S M / L samples apart; with S = the smallest multiple
+// of L that is >= 256 a workgroup of S threads (rounded up to whole waves) takes U S consecutive outputs,
+// thread t the outputs n0 + t + S i.  Per tap a thread then reads the filter value once for its U outputs:
+// (U + 1) / U LDS reads per fma where resample_kernel above needs two -- the kernel is LDS-bound, so that is
+// its speed.  Every output still accumulates its taps in ascending order with fmaf: the same bits.
+// Used when S <= 1024 (launch_resample); resample_kernel remains for other ratios.
+__global__ __launch_bounds__(1024) void resample_phase_kernel(const ResampleArgs a, const int S, const int U) {
+  __shared__ float xs[kRsSpanFloats];
+  __shared__ float hs[kRsChunkFloats];
+  constexpr int kU = 8;
+  const int tid = threadIdx.x, nthreads = blockDim.x, b = blockIdx.y;
+  const int opb = S * U;
+  const long long n0 = (long long)blockIdx.x * opb;
+  if (n0 >= a.out_stride) return;
+  int n_out = a.out_lengths[b];
+  if (n_out < 0) n_out = 0;
+  if (n_out > a.out_stride) n_out = (int)a.out_stride;
+  float* __restrict__ o = a.out + (long long)b * a.out_stride;
+  long long n_end = n0 + opb;
+  if (n_end > a.out_stride) n_end = a.out_stride;
+  if (n0 >= n_out) {                                   // behind the utterance: zeros
+    for (long long n = n0 + tid; n < n_end; n += nthreads) o[n] = 0.f;
+    return;
+  }
+  int len_in = a.lengths[b];
+  if (len_in < 0) len_in = 0;
+  const long long off = a.offsets ? a.offsets[b] : (long long)b * a.row_stride;
+  Source src;
+  src.w = a.pcm ? nullptr : a.wav + off;
+  src.pcm = a.pcm ? a.pcm + off : nullptr;
+  src.ch = a.channels;
+  const long long n_last = (n_end < n_out ? n_end : n_out) - 1;
+  const long long lo = n0 * a.M / a.L - a.k0;
+  const long long hi = n_last * a.M / a.L - a.k0 + a.taps - 1;
+  const int span = (int)(hi - lo + 1);                 // <= kRsSpanFloats (checked by the host)
+  for (int i0 = tid; i0 < span; i0 += nthreads * 8) {   // 8 loads in flight per thread, branch-free (Source::gather)
+    int idx[8];
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long k = lo + i0 + nthreads * u;
+      idx[u] = (i0 + nthreads * u < span && k >= 0 && k < len_in) ? (int)k : -1;
+    }
+    src.gather<8>(idx, len_in, v);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + nthreads * u < span) xs[i0 + nthreads * u] = v[u];
+  }
+  // this thread's phase and the window starts of its outputs (slots behind the last output redo output 0's window)
+  const bool worker = tid < S && n0 + tid <= n_last;
+  const long long t = (n0 + (worker ? tid : 0)) * a.M;
+  const long long base = t / a.L;
+  const int phase = (int)(t - base * a.L);
+  const int stride = S / a.L * a.M;                    // window distance of two outputs S apart
+  int xoff[kU];
+  float acc[kU];
+#pragma unroll
+  for (int u = 0; u < kU; ++u) {
+    const bool live = worker && u < U && n0 + tid + (long long)S * u <= n_last;
+    xoff[u] = (int)(base - a.k0 - lo) + (live ? stride * u : 0);
+    acc[u] = 0.f;
+  }
+  const int rows = kRsChunkFloats / a.L;               // filter rows per chunk (>= 1)
+  for (int j0 = 0; j0 < a.taps; j0 += rows) {
+    const int r_here = (a.taps - j0 < rows) ? a.taps - j0 : rows;
+    __syncthreads();                                   // previous chunk consumed (first pass: xs written)
+    for (int i = tid; i < r_here * a.L; i += nthreads) hs[i] = a.table[(long long)j0 * a.L + i];
+    __syncthreads();
+    const float* hp = hs + phase;
+    int r = 0;
+    for (; r + 4 <= r_here; r += 4) {
+      const float h0 = hp[r * a.L], h1 = hp[(r + 1) * a.L], h2 = hp[(r + 2) * a.L], h3 = hp[(r + 3) * a.L];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) {
+        const float* x = xs + xoff[u] + j0 + r;
+        acc[u] = fmaf(h0, x[0], acc[u]);
+        acc[u] = fmaf(h1, x[1], acc[u]);
+        acc[u] = fmaf(h2, x[2], acc[u]);
+        acc[u] = fmaf(h3, x[3], acc[u]);
+      }
+    }
+    for (; r < r_here; ++r) {
+      const float h0 = hp[r * a.L];
+#pragma unroll
+      for (int u = 0; u < kU; ++u) acc[u] = fmaf(h0, xs[xoff[u] + j0 + r], acc[u]);
+    }
+  }
+  if (tid < S) {
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const long long n = n0 + tid + (long long)S * u;
+      if (u < U && n < n_end) o[n] = (n < n_out) ? acc[u] : 0.f;
+    }
+  }
+}
+
 // ------------------------------------------------------------- reverberation
 // scipy.signal.fftconvolve(sample, rir, mode='same') restated as the direct sum
 //   y[n] = sum_k rir[k] * x[n + (Lr - 1) / 2 - k],   n in [0, len),
@@ -2256,6 +2353,20 @@ hipError_t launch_reverb(const ReverbArgs& a, int batch, hipStream_t stream) {
 }
 
 hipError_t launch_resample(const ResampleArgs& a, int batch, hipStream_t stream) {
+  // outputs S apart share a filter phase when L | S: S = the smallest multiple of L that fills 4 waves
+  const int S = a.L >= 256 ? a.L : (256 + a.L - 1) / a.L * a.L;
+  if (S <= 1024 && !(a.tune & 4)) {                   // (WFE_TUNE & 4: resample_kernel everywhere, for A/B)
+    // U outputs per thread: as many (<= 8) as keep the workgroup's input span inside the LDS buffer
+    int U = 8;
+    while (U > 1 && (long long)S * U * a.M / a.L + a.taps + 2 > kRsSpanFloats) --U;
+    if ((long long)S * U * a.M / a.L + a.taps + 2 <= kRsSpanFloats) {
+      const long long opb = (long long)S * U;
+      const long long gx = (a.out_stride + opb - 1) / opb;
+      hipLaunchKernelGGL(resample_phase_kernel, dim3((unsigned)(gx < 1 ? 1 : gx), batch), dim3((S + 63) / 64 * 64), 0, stream, a,
+                         S, U);
+      return hipGetLastError();
+    }
+  }
   const long long gx = (a.out_stride + a.out_per_block - 1) / a.out_per_block;
   hipLaunchKernelGGL(resample_kernel, dim3((unsigned)(gx < 1 ? 1 : gx), batch), dim3(256), 0, stream, a);
   return hipGetLastError();
