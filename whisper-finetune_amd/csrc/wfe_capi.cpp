@@ -543,6 +543,7 @@ int wfe_reverb(wfe_handle h, const float* wav, const int64_t* offsets, const int
     a.out = out + (long long)s.begin * out_stride;
     a.out_stride = out_stride;
     a.peaks = h->d_peaks;
+    a.tune = h->tune;
     HIP_TRY(h, hipMemsetAsync(h->d_peaks, 0, sizeof(unsigned) * 2 * kMaxBatchPerLaunch, stream));
     HIP_TRY(h, wfe::launch_reverb(a, s.count, stream));
   }

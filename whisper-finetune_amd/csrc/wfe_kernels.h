@@ -118,6 +118,7 @@ struct ReverbArgs {
   float* out;                    // (batch, out_stride), rows zero behind lengths[b]
   long long out_stride;
   unsigned* peaks;               // (batch x 2) max |x|, max |y| as float bits (non-negative floats order as uints)
+  int tune;                      // experiment switches (WFE_TUNE)
 };
 hipError_t launch_reverb(const ReverbArgs& a, int batch, hipStream_t stream);
 

@@ -2200,7 +2200,116 @@ __global__ __launch_bounds__(1024) void resample_phase_kernel(const ResampleArgs
 // second pass.  One workgroup = 2048 outputs of one utterance (thread t owns
 // n0 + t + 256 i): per chunk of 512 taps the taps and the input span they touch are
 // staged in LDS; lanes read consecutive addresses.
+// Sliding-window form (round 2).  reverb_kernel below reads one input sample from LDS per fma (thread t owns
+// outputs n0 + t + 256 i) and is LDS-bound at 36 TFLOP/s.  Here thread t owns the 8 CONSECUTIVE outputs
+// n0 + 8 t + i: from one tap to the next its 8 inputs shift by one sample, so the window lives in registers
+// (rotated through an unrolled block of 8 taps) and a tap costs ONE new LDS read for 8 fma, plus the tap value
+// (a broadcast read, four taps per ds_read_b128).  The lanes' reads are 8 samples apart: the span is stored with
+// one pad word per 8 (index s + s / 8, lane stride 9) so that they fall on distinct banks.  Every output still
+// accumulates its taps in ascending order with fmaf: the same bits as reverb_kernel (tools/reverb_ab.py).
 constexpr int kRvOut = 2048, kRvTaps = 512;
+__device__ __forceinline__ int rv_pad(int s) { return s + (s >> 3); }
+__global__ __launch_bounds__(256) void reverb_window_kernel(const ReverbArgs a) {
+  constexpr int kSpan = kRvOut + kRvTaps + 8;
+  __shared__ float xs[kSpan + kSpan / 8 + 8];
+  __shared__ __attribute__((aligned(16))) float hs[kRvTaps];
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const long long n0 = (long long)blockIdx.x * kRvOut;
+  if (n0 >= a.out_stride) return;
+  int len = a.lengths[b];
+  if (len < 0) len = 0;
+  if (len > a.out_stride) len = (int)a.out_stride;
+  float* __restrict__ o = a.out + (long long)b * a.out_stride;
+  long long n_end = n0 + kRvOut;
+  if (n_end > a.out_stride) n_end = a.out_stride;
+  if (n0 >= len) {
+    for (long long n = n0 + tid; n < n_end; n += 256) o[n] = 0.f;
+    return;
+  }
+  const float* __restrict__ x = a.wav + (a.offsets ? a.offsets[b] : (long long)b * a.row_stride);
+  const int ri = a.rir_index[b];
+  if (ri < 0) {                                        // no reverb for this utterance
+    for (long long n = n0 + tid; n < n_end; n += 256) o[n] = n < len ? x[n] : 0.f;
+    return;
+  }
+  Source xsrc;
+  xsrc.w = x;
+  xsrc.pcm = nullptr;
+  xsrc.ch = 1;
+  const long long h0 = a.rir_off[ri];
+  const int lr = (int)(a.rir_off[ri + 1] - h0);
+  const int c = (lr - 1) / 2;
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  for (int k0 = 0; k0 < lr; k0 += kRvTaps) {
+    const int kc = (lr - k0 < kRvTaps) ? lr - k0 : kRvTaps;
+    const int kc8 = (kc + 7) & ~7;                     // taps of the chunk, padded with zeros to whole blocks of 8
+    // inputs touched by taps [k0, k0 + kc8): s = n + c - k, n in [n0, n0 + 2048); position i of the span is input s_lo + i
+    const long long s_lo = n0 + c - (k0 + kc8 - 1);
+    const int span = kRvOut + kc8 - 1;
+    __syncthreads();
+    for (int i0 = tid; i0 < span; i0 += 256 * 10) {    // the whole span in one batch of 10 loads per thread
+      int idx[10];
+      float v[10];
+#pragma unroll
+      for (int u = 0; u < 10; ++u) {
+        const long long s2 = s_lo + i0 + 256 * u;
+        idx[u] = (i0 + 256 * u < span && s2 >= 0 && s2 < len) ? (int)s2 : -1;
+      }
+      xsrc.gather<10>(idx, len, v);
+#pragma unroll
+      for (int u = 0; u < 10; ++u)
+        if (i0 + 256 * u < span) xs[rv_pad(i0 + 256 * u)] = v[u];
+    }
+    for (int i = tid; i < kc8; i += 256) hs[i] = i < kc ? a.rir[h0 + k0 + i] : 0.f;   // (fmaf(0, x, acc) == acc: x is finite or the output is NaN anyway)
+    __syncthreads();
+    // tap kk of output 8 t + i reads span position 8 t + i + d, d = kc8 - 1 - kk; d runs over whole blocks 8 g + 7 .. 8 g
+    const float* __restrict__ xw = xs + 9 * tid;       // rv_pad(8 t + e) = 9 t + e + (e >> 3)
+    float w[8];
+    {
+      const int d = kc8 - 1;                           // == 7 mod 8
+#pragma unroll
+      for (int i = 0; i < 8; ++i) w[i] = xw[rv_pad(i + d)];
+    }
+    for (int kb = 0; kb < kc8; kb += 8) {
+      const f32x4 ha = *reinterpret_cast<const f32x4*>(hs + kb), hb = *reinterpret_cast<const f32x4*>(hs + kb + 4);
+      const int g9 = 9 * ((kc8 - 8 - kb) >> 3);        // the block's new samples sit at e = 8 g + 6 .. 8 g - 1
+      const float* __restrict__ xn = xw + g9;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const float hv = r < 4 ? ha[r & 3] : hb[r & 3];
+        // window before tap kb + r: w[(i - r) & 7] holds the input of output i
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = fmaf(hv, w[(i - r) & 7], acc[i]);
+        // shift by one sample: output 0's next input replaces the slot output 7 used
+        // e = 8 g + 6 - r; for r = 7: e = 8 g - 1, one pad word back (nothing follows the chunk's last tap)
+        w[(7 - r) & 7] = (r < 7) ? xn[6 - r] : (g9 > 0 ? xn[-2] : 0.f);
+      }
+    }
+  }
+  float pk_y = 0.f, pk_x = 0.f;
+  const long long nb = n0 + 8 * tid;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const long long n = nb + i;
+    if (n < n_end) {
+      const bool in = n < len;
+      o[n] = in ? acc[i] : 0.f;
+      if (in) {
+        pk_y = fmaxf(pk_y, fabsf(acc[i]));
+        pk_x = fmaxf(pk_x, fabsf(x[n]));
+      }
+    }
+  }
+  pk_y = wave_reduce<true>(pk_y);
+  pk_x = wave_reduce<true>(pk_x);
+  if ((tid & 63) == 0) {                               // NaN peaks (NaN input) are not propagated: max ignores them
+    atomicMax(a.peaks + 2 * b, __float_as_uint(pk_x));
+    atomicMax(a.peaks + 2 * b + 1, __float_as_uint(pk_y));
+  }
+}
+
 __global__ __launch_bounds__(256) void reverb_kernel(const ReverbArgs a) {
   __shared__ float xs[kRvOut + kRvTaps];
   __shared__ float hs[kRvTaps];
@@ -2343,7 +2452,10 @@ hipError_t launch_waveform(const FrontArgs& a, int batch, float* out, int* out_l
 
 hipError_t launch_reverb(const ReverbArgs& a, int batch, hipStream_t stream) {
   const long long gx = (a.out_stride + kRvOut - 1) / kRvOut;
-  hipLaunchKernelGGL(reverb_kernel, dim3((unsigned)(gx < 1 ? 1 : gx), batch), dim3(256), 0, stream, a);
+  if (a.tune & 4)                                       // (WFE_TUNE & 4: round 1's kernel, for A/B)
+    hipLaunchKernelGGL(reverb_kernel, dim3((unsigned)(gx < 1 ? 1 : gx), batch), dim3(256), 0, stream, a);
+  else
+    hipLaunchKernelGGL(reverb_window_kernel, dim3((unsigned)(gx < 1 ? 1 : gx), batch), dim3(256), 0, stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   long long sx = (a.out_stride + 256 * 8 - 1) / (256 * 8);
