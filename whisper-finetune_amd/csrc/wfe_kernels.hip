@@ -1258,6 +1258,10 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
         if (v4 < kBlockSamples / 4) {
           const int q = 4 * v4;                 // 4 | 160, so the four share q / 160
           const int base = q + q / kHop;
+#ifdef WFE_ABLATE_STAGE_WRITES                  // diagnostic (wrong results): lane-consecutive words instead, to read the counters
+          lds[v4 + 0] = buf[it][0], lds[v4 + 2624] = buf[it][1], lds[v4 + 5248] = buf[it][2], lds[v4 + 7872] = buf[it][3];
+          continue;
+#endif
           lds[base + 0] = buf[it][0];
           lds[base + 1] = buf[it][1];
           lds[base + 2] = buf[it][2];
