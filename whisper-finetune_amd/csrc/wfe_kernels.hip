@@ -56,6 +56,17 @@ constexpr int kStampRow = 16;   // 0..5 phase boundaries, 6 hardware id, 7 k-loo
 #define WFE_STAMP(i) do {} while (0)
 #endif
 
+// Diagnostic builds only (make variant DEFS=-DWFE_ABLATE=mask; wrong results): parts of kernel 1 removed to price
+// them -- 1 the staging's global loads, 2 butterflies, 4 mel MFMAs, 8 log, 16 statistics reductions, 32 output stores.
+#ifndef WFE_ABLATE
+#define WFE_ABLATE 0
+#endif
+// Twiddle slots in LDS: kSlots k-steps of the table are parked at a time.  With 2 slots the workgroup
+// needs a barrier behind every k-step, with 4 (written 3 steps ahead instead of 2) behind every other one.
+// Measured equal (4 slots 0.5 % slower, 10 KB more LDS): the barriers are not what the k-loop waits for.
+#ifndef WFE_SLOTS
+#define WFE_SLOTS 2
+#endif
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using f32x3 = __attribute__((ext_vector_type(3))) float;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
@@ -1101,7 +1112,8 @@ __device__ __forceinline__ void stage_augmented(const FrontArgs& a, const ChainH
 template <int NMT, bool POWER, bool AUG, int BANK>
 __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   // waveform image | twiddle slots, reused as the output tile after the k-loop
-  constexpr int kAuxTile = (16 * NMT * kTileStride > 2 * kDftStepFloats) ? 16 * NMT * kTileStride : 2 * kDftStepFloats;
+  constexpr int kSlots = WFE_SLOTS;                       // 2 or 4
+  constexpr int kAuxTile = (16 * NMT * kTileStride > kSlots * kDftStepFloats) ? 16 * NMT * kTileStride : kSlots * kDftStepFloats;
   constexpr int kAuxFloats = (AUG && kAuxTile < kStageAuxFloats) ? kStageAuxFloats : kAuxTile;   // (AUG: stage_contiguous)
   __shared__ __attribute__((aligned(16))) float lds[kLdsWaveFloats + kAuxFloats];
   const int tid = threadIdx.x;
@@ -1186,19 +1198,23 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   auto tw_load = [&](int f4_index) {       // float4 number f4_index + tid of the table
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(tw_rsrc, tw_lane, f4_index * 16, 0));
   };
-  f32x4* const slots = reinterpret_cast<f32x4*>(lds + kLdsWaveFloats);       // 2 x 512 float4
-  f32x4 g0, g1, g2, g3;
-  // three staging sets in rotation: the twiddles of step s+4 are requested in step s and
-  // parked in LDS in step s+2 (two whole steps for the L2 round trip under load)
+  f32x4* const slots = reinterpret_cast<f32x4*>(lds + kLdsWaveFloats);       // kSlots x 512 float4
+  // k-step s parks A(s + kAhead) in LDS (slot (s + kAhead) mod kSlots) and requests A(s + kAhead + 2) from L2:
+  // three register sets in rotation, two whole steps for the L2 round trip under load.  A(0) .. A(kAhead - 1)
+  // are parked before the loop.
+  constexpr int kAhead = kSlots == 2 ? 2 : 3;
+  f32x4 gp[2 * kAhead];
   f32x4 G[3][2];
   auto request_twiddles = [&]() {
-    g0 = tw_load(0), g1 = tw_load(256), g2 = tw_load(512), g3 = tw_load(768);
-    G[1][0] = tw_load(1024);               // A(2), written out in step 0
-    G[1][1] = tw_load(1280);
-    G[2][0] = tw_load(1536);               // A(3), written out in step 1
-    G[2][1] = tw_load(1792);
-    G[0][0] = G[1][0];
-    G[0][1] = G[1][1];
+#pragma unroll
+    for (int i = 0; i < 2 * kAhead; ++i) gp[i] = tw_load(256 * i);
+#pragma unroll
+    for (int k = kAhead; k < kAhead + 2; ++k) {          // A(kAhead), A(kAhead + 1): written out in steps 0 and 1
+      G[k % 3][0] = tw_load(512 * k);
+      G[k % 3][1] = tw_load(512 * k + 256);
+    }
+    G[(kAhead + 2) % 3][0] = G[kAhead % 3][0];           // (defined; overwritten in step 0)
+    G[(kAhead + 2) % 3][1] = G[kAhead % 3][1];
   };
   if (!AUG) request_twiddles();            // (AUG: after the staging, which wants the 32 registers itself)
 
@@ -1250,7 +1266,11 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
 #pragma unroll
       for (int it = 0; it < kIters; ++it) {
         const int v4 = tid + 256 * it;
+#if WFE_ABLATE & 1
+        buf[it] = f32x4{0.f, 0.f, 0.f, (float)v4};
+#else
         if (v4 < kBlockSamples / 4) buf[it] = src[v4];
+#endif
       }
 #pragma unroll
       for (int it = 0; it < kIters; ++it) {
@@ -1293,10 +1313,8 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
     }
   }
   if (AUG) request_twiddles();
-  slots[tid] = g0;
-  slots[256 + tid] = g1;
-  slots[512 + tid] = g2;
-  slots[768 + tid] = g3;
+#pragma unroll
+  for (int i = 0; i < 2 * kAhead; ++i) slots[256 * i + tid] = gp[i];
   WFE_STAMP(1);
   __syncthreads();
   WFE_STAMP(2);
@@ -1363,8 +1381,8 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   for (int s = 0; s < kSteps; ++s) {
     Frag7(&Rc)[4] = (s & 1) ? Rb : Ra;
     Frag7(&Rn)[4] = (s & 1) ? Ra : Rb;
-    const bool next = s + 1 < kSteps, stage = s + 2 < kSteps;
-    const f32x4* nslot = slots + ((s + 1) & 1) * 512 + lane;
+    const bool next = s + 1 < kSteps, stage = s + kAhead < kSteps;
+    const f32x4* nslot = slots + ((s + 1) % kSlots) * 512 + lane;
     float e[2], o[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -1375,15 +1393,15 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
       acc[g][bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rc[g].at(bt), (g & 1) ? o[g >> 1] : e[g >> 1], acc[g][bt],
                                                         0, 0, 0);
     };
-    f32x4(&Gw)[2] = G[(s + 1) % 3];         // holds A(s+2), requested during step s-2
-    f32x4(&Gr)[2] = G[s % 3];               // receives A(s+4)
+    f32x4(&Gw)[2] = G[(s + kAhead) % 3];        // holds A(s + kAhead), requested during step s-2
+    f32x4(&Gr)[2] = G[(s + kAhead + 2) % 3];    // receives A(s + kAhead + 2)
     // the 16 requests of a step, one behind each of the first 16 MFMAs (a clump of
     // them between two MFMAs idles the matrix pipe for the clump's issue time)
     auto request = [&](int i) {
-      if (i < 2) {                                          // global -> registers, A(s+3)
-        if (s + 4 < kSteps) Gr[i] = tw_load((s + 4) * 512 + 256 * i);
-      } else if (i < 4) {                                   // registers -> LDS, A(s+2)
-        if (stage) slots[(s & 1) * 512 + 256 * (i - 2) + tid] = Gw[i - 2];
+      if (i < 2) {                                          // global -> registers, A(s + kAhead + 2)
+        if (s + kAhead + 2 < kSteps) Gr[i] = tw_load((s + kAhead + 2) * 512 + 256 * i);
+      } else if (i < 4) {                                   // registers -> LDS, A(s + kAhead)
+        if (stage) slots[((s + kAhead) % kSlots) * 512 + 256 * (i - 2) + tid] = Gw[i - 2];
       } else if (i < 12) {                                  // LDS -> registers, fragments of A(s+1)
         const int g = (i - 4) >> 1;
         if (next) {
@@ -1404,7 +1422,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
       }
     }
 #ifdef WFE_STAMPS
-    if (next) {
+    if (next && (kSlots == 2 || (s & 1))) {
       unsigned long long tb0, tb1;
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tb0)::"memory");
       __syncthreads();
@@ -1412,7 +1430,9 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
       barrier_cycles += tb1 - tb0;
     }
 #else
-    if (next) __syncthreads();
+    // 2 slots: behind every step.  4 slots: what step s reads and overwrites was written / read in step s - 2,
+    // and a barrier behind every odd step separates any two steps that far apart.
+    if (next && (kSlots == 2 || (s & 1))) __syncthreads();
 #endif
   }
 
@@ -1456,9 +1476,14 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
       const f32x2 se = hh ? __builtin_shufflevector(acc[1][bt], acc[1][bt], 2, 3) : __builtin_shufflevector(acc[1][bt], acc[1][bt], 0, 1);
       const f32x2 co = hh ? __builtin_shufflevector(acc[2][bt], acc[2][bt], 2, 3) : __builtin_shufflevector(acc[2][bt], acc[2][bt], 0, 1);
       const f32x2 so = hh ? __builtin_shufflevector(acc[3][bt], acc[3][bt], 2, 3) : __builtin_shufflevector(acc[3][bt], acc[3][bt], 0, 1);
+#if WFE_ABLATE & 2
+      p0[hh] = ce + so;                         // (all four GEMMs stay live)
+      p1[hh] = se + co;
+#else
       const f32x2 rp = ce + co, ip = se + so, rm = ce - co, im = se - so;
       p0[hh] = __builtin_elementwise_fma(rp, rp, ip * ip);
       p1[hh] = __builtin_elementwise_fma(rm, rm, im * im);
+#endif
     }
     P[0][bt] = __builtin_shufflevector(p0[0], p0[1], 0, 1, 2, 3);
     P[1][bt] = __builtin_shufflevector(p1[0], p1[1], 0, 1, 2, 3);
@@ -1494,7 +1519,11 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
           if (((BANK == 1 ? kMelMask80[f * 7 + bt] : kMelMask128[f * 7 + bt]) >> mt) & 1u) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
+#if WFE_ABLATE & 4
+              m[mt][r] += wv[f][bt][mt][r] + P[f][bt][r];
+#else
               m[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[f][bt][mt][r], P[f][bt][r], m[mt], 0, 0, 0);
+#endif
           }
   } else {
 #pragma unroll
@@ -1551,8 +1580,10 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
     pmax = __builtin_fmaxf(__builtin_fmaxf(pmax, hi), hi3);
     pmin = __builtin_fminf(__builtin_fminf(pmin, lo), lo3);
   }
+#if !(WFE_ABLATE & 16)
   pmax = wave_reduce<true>(frame_ok ? pmax : -INFINITY);
   pmin = wave_reduce<false>(frame_ok ? pmin : INFINITY);
+#endif
   // (a wave without a valid frame leaves -inf / +inf, as before)
   const float wmax = pmax == -INFINITY ? -INFINITY : log10_floor(pmax);
   const float wmin = pmin == INFINITY ? INFINITY : log10_floor(pmin);
@@ -1562,7 +1593,11 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
     for (int r = 0; r < 4; ++r) {
       const int mel = 16 * mt + 4 * kk + r;
       // (v + 4) / 4 as one fma: v / 4 + 1 rounds once, to the same float32 as (v + 4) * 0.25
+#if WFE_ABLATE & 8
+      tile[mel * kTileStride + wave * 16 + jl] = m[mt][r];
+#else
       tile[mel * kTileStride + wave * 16 + jl] = __builtin_fmaf(log10_floor(m[mt][r]), 0.25f, 1.0f);
+#endif
     }
   if (lane == 0) {
     float* st = a.tile_stats + ((long long)b * nblk + blockIdx.x) * kTileStats;
@@ -1610,6 +1645,9 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
     for (int it = 0; it < kIt; ++it) {
       const int mel = it * 16 + (tid >> 4), c4 = tid & 15;
       if (mel < a.n_mel && 4 * c4 < frames_here)        // T % 4 == 0: a float4 is all-valid or all-out
+#if WFE_ABLATE & 32
+        if (row[it][0] == 12345.678f)
+#endif
         *reinterpret_cast<f32x4*>(lo + (long long)mel * T + 4 * c4) = row[it];
     }
   } else {
