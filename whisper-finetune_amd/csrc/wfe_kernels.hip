@@ -57,7 +57,8 @@ constexpr int kStampRow = 16;   // 0..5 phase boundaries, 6 hardware id, 7 k-loo
 #endif
 
 // Diagnostic builds only (make variant DEFS=-DWFE_ABLATE=mask; wrong results): parts of kernel 1 removed to price
-// them -- 1 the staging's global loads, 2 butterflies, 4 mel MFMAs, 8 log, 16 statistics reductions, 32 output stores.
+// them -- 1 the staging's global loads, 2 butterflies, 4 mel MFMAs, 8 log, 16 statistics reductions, 32 output stores,
+// 64 the k-loop's barriers, 128 its requests (twiddle and sample traffic), 256 its e / o adds.
 #ifndef WFE_ABLATE
 #define WFE_ABLATE 0
 #endif
@@ -1386,8 +1387,13 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
     float e[2], o[2];
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
+#if WFE_ABLATE & 256
+      e[c] = xf[c];
+      o[c] = xb[c];
+#else
       e[c] = xf[c] + xb[c];
       o[c] = xf[c] - xb[c];
+#endif
     }
     auto mfma = [&](int g, int bt) {
       acc[g][bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rc[g].at(bt), (g & 1) ? o[g >> 1] : e[g >> 1], acc[g][bt],
@@ -1417,7 +1423,9 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
       mfma(m / 7, m % 7);
       __builtin_amdgcn_sched_barrier(0);
       if (m < 16) {
+#if !(WFE_ABLATE & 128)
         request(m);
+#endif
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -1432,7 +1440,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
 #else
     // 2 slots: behind every step.  4 slots: what step s reads and overwrites was written / read in step s - 2,
     // and a barrier behind every odd step separates any two steps that far apart.
-    if (next && (kSlots == 2 || (s & 1))) __syncthreads();
+    if (next && (kSlots == 2 || (s & 1)) && !(WFE_ABLATE & 64)) __syncthreads();
 #endif
   }
 
