@@ -1109,6 +1109,20 @@ __device__ __forceinline__ void stage_augmented(const FrontArgs& a, const ChainH
   report();
 }
 
+// Which 64-frame tile of utterance blockIdx.y this workgroup takes.  Workgroups are dealt round-robin to the 8
+// XCDs by their linear index (blockIdx.x fastest).  With an odd number of tiles per utterance tile tx of
+// successive utterances rotates over all XCDs; with an even number it would land on the same few, and in a batch
+// of ragged utterances -- whose early tiles are live and late tiles silent -- those XCDs would carry the launch
+// (48 tiles per utterance: 0.356 ms against 0.249 for 47 or 49, tools/xcd_parity.py).  An even count is therefore
+// skewed by the utterance index, which makes it rotate like an odd one.
+__device__ __forceinline__ int tile_of_block(int nblk) {
+#ifdef WFE_NO_SKEW
+  return (int)blockIdx.x;
+#else
+  return (nblk & 1) ? (int)blockIdx.x : (int)((blockIdx.x + blockIdx.y) % (unsigned)nblk);
+#endif
+}
+
 // ------------------------------------------------------------- kernel 1
 template <int NMT, bool POWER, bool AUG, int BANK>
 __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
@@ -1121,10 +1135,11 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int b = blockIdx.y;
-  const int t0 = blockIdx.x * kBlockFrames;
   const int n = a.n_samples;
   const int T = a.n_frames;
   const int nblk = (T + kBlockFrames - 1) / kBlockFrames;   // == gridDim.x, without the late kernarg load
+  const int tx = tile_of_block(nblk);
+  const int t0 = tx * kBlockFrames;
   // AUG: the staging outranks the partner workgroup's MFMA stream in the SIMD's arbiter (-1.4 % on the
   // augmented kernel; the k-loop at priority 2 or 3 instead, or both at 0, measured the same or worse;
   // without augmentation the staging is short and the switch costs 1.4 %)
@@ -1168,7 +1183,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
         // clamp, so kernel 2 (which knows the utterance maximum) writes its final value
         // once.  -inf marks the tile as silent; real minima are >= -10.
         if (tid < kTileStats)
-          a.tile_stats[((long long)b * nblk + blockIdx.x) * kTileStats + tid] = tid < 8 ? -INFINITY : -10.0f;
+          a.tile_stats[((long long)b * nblk + tx) * kTileStats + tid] = tid < 8 ? -INFINITY : -10.0f;
       }
       return;
     }
@@ -1182,7 +1197,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   if (a.stamps && lane == 0) {                  // which SIMD this wave ran on (tools/phase_breakdown.py)
     const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);       // HW_REG_XCC_ID[3:0]
-    unsigned long long* st = a.stamps + ((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + blockIdx.x) * 4 + wave) * kStampRow;
+    unsigned long long* st = a.stamps + ((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + tx) * 4 + wave) * kStampRow;
     st[6] = ((unsigned long long)xcc << 32) | hw;
     st[7] = 0;
   }
@@ -1228,7 +1243,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
     if (AUG) {
 #ifdef WFE_STAMPS
       stage_augmented(a, head, b, c, cops, lds, lds + kLdsWaveFloats, p0, n, len, tid,
-                                  (a.stamps && lane == 0) ? a.stamps + ((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + blockIdx.x) * 4 + wave) * kStampRow : nullptr);
+                                  (a.stamps && lane == 0) ? a.stamps + ((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + tx) * 4 + wave) * kStampRow : nullptr);
 #else
       stage_augmented(a, head, b, c, cops, lds, lds + kLdsWaveFloats, p0, n, len, tid);
 #endif
@@ -1447,7 +1462,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   WFE_STAMP(3);
 #ifdef WFE_STAMPS
   if (a.stamps && lane == 0)
-    a.stamps[((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + blockIdx.x) * 4 + wave) * kStampRow + 7] = barrier_cycles;
+    a.stamps[((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + tx) * 4 + wave) * kStampRow + 7] = barrier_cycles;
 #endif
   // Mel weight fragments of every live (bin tile, mel tile) block: all requested
   // here, ahead of the butterflies, so that the mel phase pays one L2 round trip
@@ -1608,7 +1623,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
 #endif
     }
   if (lane == 0) {
-    float* st = a.tile_stats + ((long long)b * nblk + blockIdx.x) * kTileStats;
+    float* st = a.tile_stats + ((long long)b * nblk + tx) * kTileStats;
     st[2 * wave] = wmin;                 // both entries of the frame group's pair
     st[2 * wave + 1] = wmin;
     st[8 + wave] = wmax;                 // plain stores: kernel 2 reduces the maxima (no atomics, no zeroing)
@@ -1678,6 +1693,7 @@ __global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ out, int
   __shared__ float sh[4];
   const int b = blockIdx.y;
   const int nblk = gridDim.x;
+  const int tx = tile_of_block(nblk);          // (the silent tiles this kernel writes are as unevenly spread as kernel 1's live ones)
   // log_spec.max() of the utterance (HF:161): the maximum of the per-wave maxima kernel 1 left
   float gmax = -INFINITY;
   for (int i = threadIdx.x; i < nblk * 4; i += 256)
@@ -1687,7 +1703,7 @@ __global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ out, int
   __syncthreads();
   gmax = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
   const float floor_v = gmax - 8.0f;
-  const float* bm = tile_stats + ((long long)b * nblk + blockIdx.x) * kTileStats;   // [frame group 4][wave of the pair 2]
+  const float* bm = tile_stats + ((long long)b * nblk + tx) * kTileStats;   // [frame group 4][wave of the pair 2]
   // decided per half tile (32 frames): two frame groups, each with the minima of its (up to two) waves
   const int tid = threadIdx.x;
   const float floor_g = (floor_v + 4.0f) * 0.25f;
@@ -1695,14 +1711,14 @@ __global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ out, int
     // 16-bit output: max(h, round(floor)) on the stored halves == round(max(g(v), floor))
     const bool bf = out_kind == 2;
     unsigned short* __restrict__ p16 =
-        reinterpret_cast<unsigned short*>(out) + (long long)b * n_mel * T + blockIdx.x * kBlockFrames;
+        reinterpret_cast<unsigned short*>(out) + (long long)b * n_mel * T + tx * kBlockFrames;
     const bool vec16 = (T & 3) == 0 && (reinterpret_cast<uintptr_t>(p16) & 7u) == 0;
     const unsigned hf = to16(floor_g, bf), hc = to16(fmaxf(-1.5f, floor_g), bf);
     const float ff = from16(hf, bf);
     for (int h = 0; h < 2; ++h) {
       const float lowest = fminf(fminf(bm[4 * h], bm[4 * h + 1]), fminf(bm[4 * h + 2], bm[4 * h + 3]));
       if (!(lowest < floor_v)) continue;
-      const int t0 = blockIdx.x * kBlockFrames + 32 * h;
+      const int t0 = tx * kBlockFrames + 32 * h;
       if (t0 >= T) continue;
       const int frames_here = (T - t0 < 32) ? (T - t0) : 32;
       unsigned short* __restrict__ ph = p16 + 32 * h;
@@ -1740,12 +1756,12 @@ __global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ out, int
     }
     return;
   }
-  float* __restrict__ p = out + (long long)b * n_mel * T + blockIdx.x * kBlockFrames;
+  float* __restrict__ p = out + (long long)b * n_mel * T + tx * kBlockFrames;
   const bool vec = (T & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
   for (int h = 0; h < 2; ++h) {
     const float lowest = fminf(fminf(bm[4 * h], bm[4 * h + 1]), fminf(bm[4 * h + 2], bm[4 * h + 3]));
     if (!(lowest < floor_v)) continue;
-    const int t0 = blockIdx.x * kBlockFrames + 32 * h;
+    const int t0 = tx * kBlockFrames + 32 * h;
     if (t0 >= T) continue;
     const int frames_here = (T - t0 < 32) ? (T - t0) : 32;
     float* __restrict__ ph = p + 32 * h;
