@@ -83,3 +83,34 @@ def test_stream_ordering(fe):
     want = ol.logmel_f32([2.0 * cases.synth_clip(0), 2.0 * cases.synth_clip(1)], n_mel=80)
     assert np.abs(out.cpu().numpy() - want).max() <= TOL
     assert not torch.equal(out, base)
+
+
+def test_augmented_batch_larger_than_one_launch_slice(fe):
+    """The resolve pass works per launch slice of 4096 utterances (arrival tickets, partial sums and chain heads
+    are indexed inside the slice and reused by the next one): 4200 short utterances with a NOISE op cross it, and
+    a second, smaller call follows on the same handle.  Rows equal the same utterances run in a small batch."""
+    from wfe_amd import _lib
+    from wfe_amd.frontend import NoiseBank
+    B, n = 4200, 6000
+    g = torch.Generator(device="cuda").manual_seed(6)
+    x = 0.1 * torch.randn((B, n), generator=g, device="cuda")
+    lens = torch.full((B,), n, dtype=torch.int32, device="cuda")
+    lens[4100] = 2345
+    bank = [cases.noise_clip(0, 0.2), cases.noise_clip(1, 1.0)]
+    nb = NoiseBank(bank, fe.device)
+    gain = float(np.float32(10. ** (3 / 20.)))
+
+    def plan(i):
+        j = i % 2
+        start = (i * 7) % (len(bank[j]) - n) if len(bank[j]) > n else 0
+        return [(_lib.AUG_NOISE, j, start, 10 + i % 30, 0.0), (_lib.AUG_VOLUME, 0, 0, 3, gain)]
+
+    plans = [plan(i) for i in range(B)]
+    got = fe.augment_logmel(x, lens, plans, nb, n_samples=n)
+    sel = list(range(4090, 4110)) + [0, 4199]
+    idx = torch.tensor(sel, device="cuda")
+    ref = fe.augment_logmel(x[idx].contiguous(), lens[idx].contiguous(), [plans[i] for i in sel], nb, n_samples=n)
+    again = fe.augment_logmel(x, lens, plans, nb, n_samples=n)
+    torch.cuda.synchronize()
+    assert torch.equal(got[idx], ref)
+    assert torch.equal(again, got)
