@@ -417,3 +417,26 @@ def test_reverb_matches_scipy_fftconvolve(fe):
     single = fe.reverb(flat, lens, NoiseBank(rirs, fe.device), [0] * 6, offsets=off).cpu().numpy()
     for i, w in enumerate(waves):                     # a one-tap response of 0.5: y = 0.5 x, rescaled back to x
         assert np.abs(single[i, :len(w)] - w).max() <= 1e-7
+
+
+@pytest.mark.parametrize("taps", [1, 7, 8, 9, 511, 512, 513, 1601])
+def test_reverb_window_kernel_matches_round1_kernel(monkeypatch, taps):
+    """reverb_window_kernel (8 consecutive outputs per thread, the input window in registers) accumulates every
+    output's taps in the same order as reverb_kernel (WFE_TUNE=4 keeps that one): identical bits, for impulse
+    responses around the block (8) and chunk (512) sizes, odd and even, ragged utterances, one copied through."""
+    from wfe_amd.frontend import HipFrontEnd, NoiseBank
+    monkeypatch.delenv("WFE_TUNE", raising=False)
+    fe_new = HipFrontEnd(n_mel=80, device=0)
+    monkeypatch.setenv("WFE_TUNE", "4")
+    fe_old = HipFrontEnd(n_mel=80, device=0)
+    n = 50000
+    g = torch.Generator(device="cuda").manual_seed(taps)
+    x = 0.1 * torch.randn((6, n), generator=g, device="cuda")
+    host = [n, n // 3, 5, 2049, 0, 4096]
+    lens = torch.tensor(host, dtype=torch.int32, device="cuda")
+    clips = [_rir(taps, taps), _rir(taps + 1, max(taps - 1, 1))]
+    idx = [0, 1, 0, 1, 0, -1]
+    a = fe_new.reverb(x, lens, NoiseBank(clips, fe_new.device), idx, host_lengths=host)
+    b = fe_old.reverb(x, lens, NoiseBank(clips, fe_old.device), idx, host_lengths=host)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)

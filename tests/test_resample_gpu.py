@@ -95,3 +95,26 @@ def test_resample_argument_errors(fe):
         fe.resample(x, lens, 4000000, 16000)        # decimation by 250
     with pytest.raises(ValueError):
         fe.resample(x, lens, 0, 16000)
+
+
+@pytest.mark.parametrize("orig,target", [(44100, 16000), (48000, 16000), (8000, 16000), (22050, 16000),
+                                         (16000, 44100), (24000, 16000)])
+def test_phase_sharing_kernel_matches_round1_kernel(monkeypatch, orig, target):
+    """resample_phase_kernel (a thread's outputs share one filter phase) accumulates every output's taps in the
+    same order as resample_kernel (WFE_TUNE=4 keeps that one): identical bits, on ragged lengths including an
+    utterance shorter than the filter and an empty one."""
+    from wfe_amd.frontend import HipFrontEnd
+    monkeypatch.delenv("WFE_TUNE", raising=False)
+    fe_new = HipFrontEnd(n_mel=80, device=0)
+    monkeypatch.setenv("WFE_TUNE", "4")
+    fe_old = HipFrontEnd(n_mel=80, device=0)
+    n = 3 * orig
+    g = torch.Generator(device="cuda").manual_seed(orig + target)
+    x = 0.1 * torch.randn((5, n), generator=g, device="cuda")
+    host = [n, n // 3, 7, 0, 2 * orig + 13]
+    lens = torch.tensor(host, dtype=torch.int32, device="cuda")
+    a = fe_new.resample(x, lens, orig, target, host_lengths=host)
+    b = fe_old.resample(x, lens, orig, target, host_lengths=host)
+    a, b = (a[0], b[0]) if isinstance(a, tuple) else (a, b)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
