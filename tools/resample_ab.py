@@ -32,7 +32,7 @@ def timed(fn, steps=5):
 
 
 for sr, tgt in ((44100, 16000), (48000, 16000), (8000, 16000), (22050, 16000), (11025, 16000), (32000, 16000),
-                (24000, 16000), (96000, 16000), (16000, 44100), (16000, 8000), (12345, 16000)):
+                (24000, 16000), (96000, 16000), (64000, 16000), (16000, 44100), (16000, 8000), (12345, 16000)):
     n = 30 * sr
     g = torch.Generator(device=dev).manual_seed(sr)
     x = 0.1 * torch.randn((B, n), device=dev, generator=g)

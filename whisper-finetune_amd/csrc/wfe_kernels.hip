@@ -2258,6 +2258,79 @@ __global__ __launch_bounds__(1024) void resample_phase_kernel(const ResampleArgs
   }
 }
 
+// Integer decimation (L == 1: 48 / 32 / 64 / 96 kHz -> 16 kHz), sliding-window form.  All outputs share the one
+// filter phase and output m reads the inputs M m - k0 + j: thread t owns 7 CONSECUTIVE outputs, whose inputs at one
+// tap are M apart and move by one sample from tap to tap, so the 6 M + 1 samples they span live in registers
+// (rotated through an unrolled block of 6 M + 1 taps) and a tap costs one new LDS read and one broadcast read of
+// the tap value for 7 fma, where resample_kernel needs 14.  (7, not 8, outputs: the lanes' reads are 7 M samples
+// apart, an odd or at worst twice-odd stride over the banks.)  Taps in ascending order per output: the same bits.
+template <int M>
+__global__ __launch_bounds__(256) void resample_decimate_kernel(const ResampleArgs a) {
+  constexpr int U = 7, W = (U - 1) * M + 1, kOut = 256 * U;
+  constexpr int kTapsMax = 1024;
+  __shared__ float xs[kRsSpanFloats];
+  __shared__ float hs[kTapsMax];
+  const int tid = threadIdx.x, b = blockIdx.y;
+  const long long n0 = (long long)blockIdx.x * kOut;
+  if (n0 >= a.out_stride) return;
+  int n_out = a.out_lengths[b];
+  if (n_out < 0) n_out = 0;
+  if (n_out > a.out_stride) n_out = (int)a.out_stride;
+  float* __restrict__ o = a.out + (long long)b * a.out_stride;
+  long long n_end = n0 + kOut;
+  if (n_end > a.out_stride) n_end = a.out_stride;
+  if (n0 >= n_out) {                                   // behind the utterance: zeros
+    for (long long n = n0 + tid; n < n_end; n += 256) o[n] = 0.f;
+    return;
+  }
+  int len_in = a.lengths[b];
+  if (len_in < 0) len_in = 0;
+  const long long off = a.offsets ? a.offsets[b] : (long long)b * a.row_stride;
+  Source src;
+  src.w = a.pcm ? nullptr : a.wav + off;
+  src.pcm = a.pcm ? a.pcm + off : nullptr;
+  src.ch = a.channels;
+  const int taps_p = (a.taps + W - 1) / W * W;         // whole blocks of W taps, the tail padded with zeros
+  const long long lo = n0 * M - a.k0;                  // span position i is input lo + i
+  const int span = (kOut - 1) * M + taps_p + W;        // every slot of the workgroup, live or not (host: <= kRsSpanFloats)
+  for (int i0 = tid; i0 < span; i0 += 256 * 8) {       // 8 loads in flight per thread, branch-free (Source::gather)
+    int idx[8];
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long k = lo + i0 + 256 * u;
+      idx[u] = (i0 + 256 * u < span && k >= 0 && k < len_in) ? (int)k : -1;
+    }
+    src.gather<8>(idx, len_in, v);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + 256 * u < span) xs[i0 + 256 * u] = v[u];
+  }
+  for (int i = tid; i < taps_p; i += 256) hs[i] = i < a.taps ? a.table[i] : 0.f;
+  __syncthreads();
+  const float* __restrict__ xw = xs + U * M * tid;     // output i of this thread reads xw[j + M i] at tap j
+  float w[W], acc[U];
+#pragma unroll
+  for (int r = 0; r < W; ++r) w[r] = xw[r];
+#pragma unroll
+  for (int i = 0; i < U; ++i) acc[i] = 0.f;
+  for (int jb = 0; jb < taps_p; jb += W) {
+#pragma unroll
+    for (int r = 0; r < W; ++r) {
+      const float hv = hs[jb + r];
+      // position j + M i of the window sits in slot (j + M i) mod W; jb is a multiple of W
+#pragma unroll
+      for (int i = 0; i < U; ++i) acc[i] = fmaf(hv, w[(r + M * i) % W], acc[i]);
+      w[r] = xw[jb + r + W];                           // the sample that enters as the one tap j used for output 0 leaves
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < U; ++i) {
+    const long long n = n0 + U * tid + i;
+    if (n < n_end) o[n] = (n < n_out) ? acc[i] : 0.f;
+  }
+}
+
 // ------------------------------------------------------------- reverberation
 // scipy.signal.fftconvolve(sample, rir, mode='same') restated as the direct sum
 //   y[n] = sum_k rir[k] * x[n + (Lr - 1) / 2 - k],   n in [0, len),
@@ -2533,6 +2606,21 @@ hipError_t launch_reverb(const ReverbArgs& a, int batch, hipStream_t stream) {
 hipError_t launch_resample(const ResampleArgs& a, int batch, hipStream_t stream) {
   // outputs S apart share a filter phase when L | S: S = the smallest multiple of L that fills 4 waves
   const int S = a.L >= 256 ? a.L : (256 + a.L - 1) / a.L * a.L;
+  if (a.L == 1 && !(a.tune & 4) && (a.M == 2 || a.M == 3 || a.M == 4 || a.M == 6)) {
+    // integer decimation: the sliding-window kernel, when its span and taps fit
+    const int W = 6 * a.M + 1, taps_p = (a.taps + W - 1) / W * W;
+    if (taps_p <= 1024 && (long long)(256 * 7 - 1) * a.M + taps_p + W <= kRsSpanFloats) {
+      const long long gx = (a.out_stride + 256 * 7 - 1) / (256 * 7);
+      const dim3 grid((unsigned)(gx < 1 ? 1 : gx), batch);
+      switch (a.M) {
+        case 2: hipLaunchKernelGGL(resample_decimate_kernel<2>, grid, dim3(256), 0, stream, a); break;
+        case 3: hipLaunchKernelGGL(resample_decimate_kernel<3>, grid, dim3(256), 0, stream, a); break;
+        case 4: hipLaunchKernelGGL(resample_decimate_kernel<4>, grid, dim3(256), 0, stream, a); break;
+        default: hipLaunchKernelGGL(resample_decimate_kernel<6>, grid, dim3(256), 0, stream, a); break;
+      }
+      return hipGetLastError();
+    }
+  }
   if (S <= 1024 && !(a.tune & 4)) {                   // (WFE_TUNE & 4: resample_kernel everywhere, for A/B)
     // U outputs per thread: as many (<= 8) as keep the workgroup's input span inside the LDS buffer
     int U = 8;
