@@ -98,7 +98,8 @@ def test_resample_argument_errors(fe):
 
 
 @pytest.mark.parametrize("orig,target", [(44100, 16000), (48000, 16000), (8000, 16000), (22050, 16000),
-                                         (16000, 44100), (24000, 16000), (32000, 16000), (96000, 16000), (64000, 16000)])
+                                         (16000, 44100), (24000, 16000), (32000, 16000), (96000, 16000), (64000, 16000),
+                                         (12000, 16000), (16000, 8000), (16000, 32000), (16000, 24000)])
 def test_phase_sharing_kernel_matches_round1_kernel(monkeypatch, orig, target):
     """resample_phase_kernel (a thread's outputs share one filter phase) accumulates every output's taps in the
     same order as resample_kernel (WFE_TUNE=4 keeps that one): identical bits, on ragged lengths including an

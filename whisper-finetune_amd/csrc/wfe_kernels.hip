@@ -2258,29 +2258,33 @@ __global__ __launch_bounds__(1024) void resample_phase_kernel(const ResampleArgs
   }
 }
 
-// Integer decimation (L == 1: 48 / 32 / 64 / 96 kHz -> 16 kHz), sliding-window form.  All outputs share the one
-// filter phase and output m reads the inputs M m - k0 + j: thread t owns 7 CONSECUTIVE outputs, whose inputs at one
-// tap are M apart and move by one sample from tap to tap, so the 6 M + 1 samples they span live in registers
-// (rotated through an unrolled block of 6 M + 1 taps) and a tap costs one new LDS read and one broadcast read of
-// the tap value for 7 fma, where resample_kernel needs 14.  (7, not 8, outputs: the lanes' reads are 7 M samples
-// apart, an odd or at worst twice-odd stride over the banks.)  Taps in ascending order per output: the same bits.
+// Few filter phases (L <= 4: 48 / 32 / 64 / 96 kHz -> 16 kHz with L = 1; 8 -> 16, 24 -> 16, 12 -> 16 kHz with L = 2, 4),
+// sliding-window form.  The outputs of ONE phase p, n = p + L m, are a decimation by M of the input with the
+// filter column (p M) mod L: output m reads the inputs M m + floor(p M / L) - k0 + j.  blockIdx.z is the phase; thread t
+// owns 7 CONSECUTIVE outputs of it, whose inputs at one tap are M apart and move by one sample from tap to tap,
+// so the 6 M + 1 samples they span live in registers (rotated through an unrolled block of 6 M + 1 taps) and a
+// tap costs one new LDS read and one broadcast read of the tap value for 7 fma, where resample_kernel needs 14.
+// (7, not 8, outputs: the lanes' reads are 7 M samples apart, an odd or at worst twice-odd stride over the
+// banks.)  Taps in ascending order per output: the same bits.
 template <int M>
 __global__ __launch_bounds__(256) void resample_decimate_kernel(const ResampleArgs a) {
   constexpr int U = 7, W = (U - 1) * M + 1, kOut = 256 * U;
   constexpr int kTapsMax = 1024;
   __shared__ float xs[kRsSpanFloats];
   __shared__ float hs[kTapsMax];
-  const int tid = threadIdx.x, b = blockIdx.y;
-  const long long n0 = (long long)blockIdx.x * kOut;
-  if (n0 >= a.out_stride) return;
+  const int tid = threadIdx.x, b = blockIdx.y, L = a.L, ph = blockIdx.z;
+  const long long m0 = (long long)blockIdx.x * kOut;   // first output of this workgroup, counted within the phase
+  const long long n_first = ph + L * m0;
+  if (n_first >= a.out_stride) return;
   int n_out = a.out_lengths[b];
   if (n_out < 0) n_out = 0;
   if (n_out > a.out_stride) n_out = (int)a.out_stride;
   float* __restrict__ o = a.out + (long long)b * a.out_stride;
-  long long n_end = n0 + kOut;
-  if (n_end > a.out_stride) n_end = a.out_stride;
-  if (n0 >= n_out) {                                   // behind the utterance: zeros
-    for (long long n = n0 + tid; n < n_end; n += 256) o[n] = 0.f;
+  if (n_first >= n_out) {                              // behind the utterance: zeros
+    for (int i = tid; i < kOut; i += 256) {
+      const long long n = ph + L * (m0 + i);
+      if (n < a.out_stride) o[n] = 0.f;
+    }
     return;
   }
   int len_in = a.lengths[b];
@@ -2291,7 +2295,8 @@ __global__ __launch_bounds__(256) void resample_decimate_kernel(const ResampleAr
   src.pcm = a.pcm ? a.pcm + off : nullptr;
   src.ch = a.channels;
   const int taps_p = (a.taps + W - 1) / W * W;         // whole blocks of W taps, the tail padded with zeros
-  const long long lo = n0 * M - a.k0;                  // span position i is input lo + i
+  const int col = ph * M % L;                          // the filter column of output n is (n M) mod L
+  const long long lo = m0 * M + (long long)ph * M / L - a.k0;   // span position i is input lo + i
   const int span = (kOut - 1) * M + taps_p + W;        // every slot of the workgroup, live or not (host: <= kRsSpanFloats)
   for (int i0 = tid; i0 < span; i0 += 256 * 8) {       // 8 loads in flight per thread, branch-free (Source::gather)
     int idx[8];
@@ -2306,7 +2311,7 @@ __global__ __launch_bounds__(256) void resample_decimate_kernel(const ResampleAr
     for (int u = 0; u < 8; ++u)
       if (i0 + 256 * u < span) xs[i0 + 256 * u] = v[u];
   }
-  for (int i = tid; i < taps_p; i += 256) hs[i] = i < a.taps ? a.table[i] : 0.f;
+  for (int i = tid; i < taps_p; i += 256) hs[i] = i < a.taps ? a.table[(long long)i * L + col] : 0.f;
   __syncthreads();
   const float* __restrict__ xw = xs + U * M * tid;     // output i of this thread reads xw[j + M i] at tap j
   float w[W], acc[U];
@@ -2326,8 +2331,8 @@ __global__ __launch_bounds__(256) void resample_decimate_kernel(const ResampleAr
   }
 #pragma unroll
   for (int i = 0; i < U; ++i) {
-    const long long n = n0 + U * tid + i;
-    if (n < n_end) o[n] = (n < n_out) ? acc[i] : 0.f;
+    const long long n = ph + L * (m0 + U * tid + i);
+    if (n < a.out_stride) o[n] = (n < n_out) ? acc[i] : 0.f;
   }
 }
 
@@ -2606,13 +2611,15 @@ hipError_t launch_reverb(const ReverbArgs& a, int batch, hipStream_t stream) {
 hipError_t launch_resample(const ResampleArgs& a, int batch, hipStream_t stream) {
   // outputs S apart share a filter phase when L | S: S = the smallest multiple of L that fills 4 waves
   const int S = a.L >= 256 ? a.L : (256 + a.L - 1) / a.L * a.L;
-  if (a.L == 1 && !(a.tune & 4) && (a.M == 2 || a.M == 3 || a.M == 4 || a.M == 6)) {
-    // integer decimation: the sliding-window kernel, when its span and taps fit
+  if (a.L <= 4 && !(a.tune & 4) && (a.M == 1 || a.M == 2 || a.M == 3 || a.M == 4 || a.M == 6)) {
+    // few phases: the sliding-window kernel, one grid layer per phase, when its span and taps fit
     const int W = 6 * a.M + 1, taps_p = (a.taps + W - 1) / W * W;
     if (taps_p <= 1024 && (long long)(256 * 7 - 1) * a.M + taps_p + W <= kRsSpanFloats) {
-      const long long gx = (a.out_stride + 256 * 7 - 1) / (256 * 7);
-      const dim3 grid((unsigned)(gx < 1 ? 1 : gx), batch);
+      const long long per_phase = (a.out_stride + a.L - 1) / a.L;
+      const long long gx = (per_phase + 256 * 7 - 1) / (256 * 7);
+      const dim3 grid((unsigned)(gx < 1 ? 1 : gx), batch, a.L);
       switch (a.M) {
+        case 1: hipLaunchKernelGGL(resample_decimate_kernel<1>, grid, dim3(256), 0, stream, a); break;
         case 2: hipLaunchKernelGGL(resample_decimate_kernel<2>, grid, dim3(256), 0, stream, a); break;
         case 3: hipLaunchKernelGGL(resample_decimate_kernel<3>, grid, dim3(256), 0, stream, a); break;
         case 4: hipLaunchKernelGGL(resample_decimate_kernel<4>, grid, dim3(256), 0, stream, a); break;
