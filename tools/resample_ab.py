@@ -13,7 +13,7 @@ from wfe_amd.frontend import HipFrontEnd  # noqa: E402
 
 os.environ.pop("WFE_TUNE", None)
 fe_new = HipFrontEnd(n_mel=80, device=0)
-os.environ["WFE_TUNE"] = "4"
+os.environ["WFE_TUNE"] = os.environ.get("AB_OLD_TUNE", "4")
 fe_old = HipFrontEnd(n_mel=80, device=0)
 dev = fe_new.device
 B = 64
@@ -49,6 +49,7 @@ for sr, tgt in ((44100, 16000), (48000, 16000), (8000, 16000), (22050, 16000), (
     y_new = y_new[0] if isinstance(y_new, tuple) else y_new
     y_old = y_old[0] if isinstance(y_old, tuple) else y_old
     same = torch.equal(y_new, y_old)
+    diff = float((y_new - y_old).abs().max())
     t_new = timed(lambda: fe_new.resample(x, lens, sr, tgt, host_lengths=host))
     t_old = timed(lambda: fe_old.resample(x, lens, sr, tgt, host_lengths=host))
-    print(f"{sr:6d} -> {tgt:6d}: identical {same}   phase-sharing {t_new:7.3f} ms   resample_kernel {t_old:7.3f} ms   x{t_old / t_new:.2f}")
+    print(f"{sr:6d} -> {tgt:6d}: identical {same!s:5} (max diff {diff:.1e})   round 2 {t_new:7.3f} ms   resample_kernel {t_old:7.3f} ms   x{t_old / t_new:.2f}")

@@ -43,6 +43,10 @@ struct wfe_context {
   struct RsTable {
     float* d = nullptr;
     int L = 0, M = 0, taps = 0, k0 = 0;
+    // the same filter in the order resample_mfma_kernel reads it (ratios with >= 64 phases), else null
+    float* d_frag = nullptr;
+    int* d_meta = nullptr;
+    int ptiles = 0, kspan = 0, nwaves = 0;
   };
   std::map<std::pair<int, int>, RsTable> rs_tables;   // (in_rate, out_rate) -> filter on the device
   float* d_tile_stats = nullptr;            // per-tile minima / maxima of kernel 1, grows on demand
@@ -357,7 +361,11 @@ int wfe_destroy(wfe_handle h) {
   if (h->d_noise_meansq) (void)hipFree(h->d_noise_meansq);
   if (h->d_tile_stats) (void)hipFree(h->d_tile_stats);
   for (auto& kv : h->rs_tables)
+  {
     if (kv.second.d) (void)hipFree(kv.second.d);
+    if (kv.second.d_frag) (void)hipFree(kv.second.d_frag);
+    if (kv.second.d_meta) (void)hipFree(kv.second.d_meta);
+  }
   if (h->d_partials) (void)hipFree(h->d_partials);
   if (h->d_tickets) (void)hipFree(h->d_tickets);
   if (h->d_peaks) (void)hipFree(h->d_peaks);
@@ -550,6 +558,41 @@ int wfe_reverb(wfe_handle h, const float* wav, const int64_t* offsets, const int
   return WFE_OK;
 }
 
+// The polyphase filter [taps][L] as the A operand of resample_mfma_kernel: T[p][c] = table[c - floor(p M / L)][(p M) mod L]
+// (zero outside the taps), per tile of 16 phases only the k-steps (4 columns) its band touches, rounded to quads;
+// lane l of a fragment holds row l % 16, column l / 16 of the k-step, 4 consecutive k-steps per float4.
+static void build_resample_fragments(const std::vector<float>& table, int L, int M, int taps, std::vector<float>& frag,
+                                     std::vector<int>& meta, int& kspan) {
+  const int ptiles = (L + 15) / 16;
+  meta.assign(3 * (size_t)ptiles, 0);
+  frag.clear();
+  kspan = 0;
+  long long foff = 0;
+  for (int pt = 0; pt < ptiles; ++pt) {
+    const int p0 = 16 * pt, p1 = (p0 + 16 < L ? p0 + 16 : L) - 1;
+    const long long c_lo = (long long)p0 * M / L, c_hi = (long long)p1 * M / L + taps;   // [c_lo, c_hi)
+    const int kb_lo = (int)(c_lo / 4), kb_hi = (int)((c_hi + 3) / 4), nq = (kb_hi - kb_lo + 3) / 4;
+    meta[3 * pt] = kb_lo;
+    meta[3 * pt + 1] = nq;
+    meta[3 * pt + 2] = (int)foff;
+    frag.resize((size_t)(foff + nq) * 256, 0.f);
+    for (int q = 0; q < nq; ++q)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int i = 0; i < 4; ++i) {
+          const int p = p0 + (lane & 15);
+          const long long c = 4LL * (kb_lo + 4 * q + i) + (lane >> 4);
+          float v = 0.f;
+          if (p < L) {
+            const long long j = c - (long long)p * M / L;
+            if (j >= 0 && j < taps) v = table[(size_t)j * L + (size_t)((long long)p * M % L)];
+          }
+          frag[((size_t)(foff + q) * 64 + lane) * 4 + i] = v;
+        }
+    foff += nq;
+    if (4 * (kb_lo + 4 * nq) > kspan) kspan = 4 * (kb_lo + 4 * nq);
+  }
+}
+
 int wfe_resample(wfe_handle h, const void* in, int32_t pcm_channels, const int64_t* offsets, const int32_t* lengths,
                  int64_t row_stride, int32_t batch, int32_t in_rate, int32_t out_rate, float* out, int64_t out_stride,
                  const int32_t* out_lengths, void* stream_) {
@@ -582,6 +625,30 @@ int wfe_resample(wfe_handle h, const void* in, int32_t pcm_channels, const int64
     if (e != hipSuccess) {
       (void)hipFree(t.d);
       return fail(h, WFE_ERR_HIP, "resample table upload: %s", hipGetErrorString(e));
+    }
+    if (t.L >= 64) {                                   // the GEMM form: the table as matrix-core fragments
+      std::vector<float> frag;
+      std::vector<int> meta;
+      build_resample_fragments(host, t.L, t.M, t.taps, frag, meta, t.kspan);
+      t.ptiles = (t.L + 15) / 16;
+      int best = 1 << 30;
+      for (int nw = 8; nw <= 16; ++nw) {               // waves per workgroup: the least idle tile slots, then the most waves
+        const int waste = (t.ptiles + nw - 1) / nw * nw - t.ptiles;
+        if (waste <= best) best = waste, t.nwaves = nw;
+      }
+      if (t.ptiles < 8) t.nwaves = t.ptiles;
+      if (15LL * t.M + t.kspan <= wfe::kRsMfmaSpanFloats && frag.size() <= (64u << 20)) {
+        hipError_t e1 = hipMalloc(&t.d_frag, frag.size() * sizeof(float));
+        hipError_t e2 = e1 == hipSuccess ? hipMalloc(&t.d_meta, meta.size() * sizeof(int)) : e1;
+        if (e2 == hipSuccess) e2 = hipMemcpy(t.d_frag, frag.data(), frag.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e2 == hipSuccess) e2 = hipMemcpy(t.d_meta, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice);
+        if (e2 != hipSuccess) {
+          if (t.d_frag) (void)hipFree(t.d_frag);
+          if (t.d_meta) (void)hipFree(t.d_meta);
+          (void)hipFree(t.d);
+          return fail(h, WFE_ERR_HIP, "resample fragment upload: %s", hipGetErrorString(e2));
+        }
+      }
     }
     it = h->rs_tables.emplace(key, t).first;
   }
@@ -616,6 +683,11 @@ int wfe_resample(wfe_handle h, const void* in, int32_t pcm_channels, const int64
     a.k0 = t.k0;
     a.out_per_block = (int)opb;
     a.tune = h->tune;
+    a.frag = t.d_frag;
+    a.frag_meta = t.d_meta;
+    a.ptiles = t.ptiles;
+    a.kspan = t.kspan;
+    a.nwaves = t.nwaves;
     HIP_TRY(h, wfe::launch_resample(a, s.count, stream));
   }
   return WFE_OK;

@@ -89,6 +89,7 @@ hipError_t launch_waveform(const FrontArgs& a, int batch, float* out, int* out_l
 // ---- resampling (CustomDataset.resample, utils/reader.py:316-319)
 constexpr int kRsSpanFloats = 14336;   // LDS floats for the input span of one workgroup
 constexpr int kRsChunkFloats = 4096;   // LDS floats for one chunk of filter rows (so L <= 4096)
+constexpr int kRsMfmaSpanFloats = 36864;   // LDS floats (144 KB) for the span of resample_mfma_kernel
 struct ResampleArgs {
   const float* wav;              // float32 input, or
   const short* pcm;              // interleaved 16-bit PCM
@@ -103,6 +104,10 @@ struct ResampleArgs {
   int L, M, taps, k0;
   int out_per_block;             // outputs per workgroup: a multiple of 256, <= 2048, span fits kRsSpanFloats
   int tune;                      // experiment switches (WFE_TUNE)
+  // the filter as the A operand of resample_mfma_kernel (wfe_capi.cpp: build_resample_fragments); null: not built
+  const float* frag;             // per tile of 16 phases: [quads of k-steps][64 lanes][4] floats
+  const int* frag_meta;          // per tile: first k-step, quads of k-steps, offset into frag (in 64 x float4)
+  int ptiles, kspan, nwaves;     // tiles of 16 phases; LDS columns the widest tile reaches; waves per workgroup
 };
 hipError_t launch_resample(const ResampleArgs& a, int batch, hipStream_t stream);
 

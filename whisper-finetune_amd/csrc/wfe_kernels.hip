@@ -2336,6 +2336,115 @@ __global__ __launch_bounds__(256) void resample_decimate_kernel(const ResampleAr
   }
 }
 
+// Rational ratios with many phases (44.1 / 22.05 / 11.025 kHz <-> 16 kHz) on the matrix cores.  The L outputs
+// n = g L + p of group g read the inputs g M + floor(p M / L) - k0 + j with the filter column (p M) mod L -- the
+// SAME banded L x K matrix T[p][c] = table[c - floor(p M / L)][(p M) mod L] (K = M - 1 + taps) for every group:
+//   out[g L + p] = sum_c T[p][c] x[g M - k0 + c],
+// a GEMM of T with the overlapping input windows of the groups.  A workgroup stages the input span of 16 GT
+// groups in LDS once; wave w takes the tiles of 16 phases w, w + nwaves, ...: v_mfma_f32_16x16x4_f32 with T as
+// the A operand (fragment order, built on the host at table creation: one 16-byte load per lane feeds 4 k-steps
+// x GT MFMAs, only the k range where the tile's band is non-zero) and the windows as B, read straight from the
+// span (lane (g, k) reads xs[g M + c + k]: one ds_read per MFMA, immediate offsets).  Products with T's zeros add
+// exact zeros; every output still sums its taps in ascending order, in float32 (the order INSIDE one 4-wide
+// k-step is the matrix core's).
+template <int GT>
+__global__ __launch_bounds__(1024) void resample_mfma_kernel(const ResampleArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float xs_dyn[];
+  float* xs = xs_dyn;
+  constexpr int G = 16 * GT;
+  const int tid = threadIdx.x, b = blockIdx.y, L = a.L, M = a.M;
+  const int nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+  const long long g0 = (long long)blockIdx.x * G;
+  const long long n_first = g0 * L;
+  if (n_first >= a.out_stride) return;
+  int n_out = a.out_lengths[b];
+  if (n_out < 0) n_out = 0;
+  if (n_out > a.out_stride) n_out = (int)a.out_stride;
+  float* __restrict__ o = a.out + (long long)b * a.out_stride;
+  long long n_end = n_first + (long long)G * L;
+  if (n_end > a.out_stride) n_end = a.out_stride;
+  if (n_first >= n_out) {                              // behind the utterance: zeros
+    for (long long n = n_first + tid; n < n_end; n += nthreads) o[n] = 0.f;
+    return;
+  }
+  int len_in = a.lengths[b];
+  if (len_in < 0) len_in = 0;
+  const long long off = a.offsets ? a.offsets[b] : (long long)b * a.row_stride;
+  Source src;
+  src.w = a.pcm ? nullptr : a.wav + off;
+  src.pcm = a.pcm ? a.pcm + off : nullptr;
+  src.ch = a.channels;
+  const long long lo = g0 * M - a.k0;                  // span position i is input lo + i
+  const int span = (G - 1) * M + a.kspan;              // (host: fits the dynamic LDS of the launch, rounded up to 4)
+  if (!a.pcm && lo >= 0) {
+    // float32 source: 16-byte buffer loads (4-byte aligned is enough; dwords behind the utterance read as 0), 4 in
+    // flight per thread -- a CU keeps a bounded NUMBER of loads in flight, so the load instruction is the unit of cost
+    const __amdgpu_buffer_rsrc_t rx = f32_rsrc(src.w, lo, (long long)len_in - lo);
+    const int nvec = (span + 3) >> 2;
+    for (int v0 = tid; v0 < nvec; v0 += nthreads * 4) {
+      f32x4 X[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) X[u] = buf_f32x4(rx, (v0 + nthreads * u) * 16);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (v0 + nthreads * u < nvec) reinterpret_cast<f32x4*>(xs)[v0 + nthreads * u] = X[u];
+    }
+  } else {
+    for (int i0 = tid; i0 < span; i0 += nthreads * 8) {  // 8 loads in flight per thread, branch-free (Source::gather)
+      int idx[8];
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long long k = lo + i0 + nthreads * u;
+        idx[u] = (i0 + nthreads * u < span && k >= 0 && k < len_in) ? (int)k : -1;
+      }
+      src.gather<8>(idx, len_in, v);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + nthreads * u < span) xs[i0 + nthreads * u] = v[u];
+    }
+  }
+  __syncthreads();
+  const f32x4* __restrict__ frag = reinterpret_cast<const f32x4*>(a.frag);
+  // Column n of tile gt is group gt * 16 + n -- or, for odd M, tiles 2 t and 2 t + 1 take the even and the odd
+  // groups of a run of 32: the 16 lanes of one k then read 2 M floats apart, an even stride with M odd, so with
+  // the neighbouring k they cover 32 distinct LDS banks (M apart, the odd stride, half of them collide).
+  const bool interleave = GT >= 2 && (M & 1);
+  auto group_of = [&](int gt) {
+    return interleave ? (gt & 1) + 2 * ((lane & 15) + 16 * (gt >> 1)) : gt * 16 + (lane & 15);
+  };
+  for (int pt = wave; pt < a.ptiles; pt += nwaves) {
+    const int kb_lo = __builtin_amdgcn_readfirstlane(a.frag_meta[3 * pt]);
+    const int nq = __builtin_amdgcn_readfirstlane(a.frag_meta[3 * pt + 1]);       // quads of k-steps
+    const int foff = __builtin_amdgcn_readfirstlane(a.frag_meta[3 * pt + 2]);     // in 64-lane float4 fragments
+    const f32x4* __restrict__ fp = frag + (long long)foff * 64 + lane;
+    const float* xb[GT];
+#pragma unroll
+    for (int gt = 0; gt < GT; ++gt) xb[gt] = xs + group_of(gt) * M + (lane >> 4) + 4 * kb_lo;
+    f32x4 acc[GT];
+#pragma unroll
+    for (int gt = 0; gt < GT; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 A = fp[0];
+    for (int q = 0; q < nq; ++q) {
+      const f32x4 An = fp[(q + 1 < nq ? q + 1 : q) * 64];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int gt = 0; gt < GT; ++gt)
+          acc[gt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i], xb[gt][16 * q + 4 * i], acc[gt], 0, 0, 0);
+      A = An;
+    }
+#pragma unroll
+    for (int gt = 0; gt < GT; ++gt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int p = 16 * pt + 4 * (lane >> 4) + i;
+        const long long n = (g0 + group_of(gt)) * L + p;
+        if (p < L && n < a.out_stride) o[n] = (n < n_out) ? acc[gt][i] : 0.f;
+      }
+  }
+}
+
 // ------------------------------------------------------------- reverberation
 // scipy.signal.fftconvolve(sample, rir, mode='same') restated as the direct sum
 //   y[n] = sum_k rir[k] * x[n + (Lr - 1) / 2 - k],   n in [0, len),
@@ -2625,6 +2734,37 @@ hipError_t launch_resample(const ResampleArgs& a, int batch, hipStream_t stream)
         case 4: hipLaunchKernelGGL(resample_decimate_kernel<4>, grid, dim3(256), 0, stream, a); break;
         default: hipLaunchKernelGGL(resample_decimate_kernel<6>, grid, dim3(256), 0, stream, a); break;
       }
+      return hipGetLastError();
+    }
+  }
+  if (a.frag && !(a.tune & (4 | 16))) {               // (WFE_TUNE & 16: without the matrix-core kernel, for A/B)
+    // many phases: the GEMM form
+    // groups of L outputs per workgroup: 64, 32 or 16 -- the most whose LDS span leaves room for two workgroups
+    // per CU (one stages while the other multiplies), else the most that fit at all
+    int gt_pick = 0;
+    for (int gt = 4; gt >= 1 && !gt_pick; gt >>= 1)
+      if ((long long)(16 * gt - 1) * a.M + a.kspan <= kRsMfmaSpanFloats / 2 + ((a.tune & 32) ? kRsMfmaSpanFloats : 0)) gt_pick = gt;
+    for (int gt = 4; gt >= 1 && !gt_pick; gt >>= 1)
+      if ((long long)(16 * gt - 1) * a.M + a.kspan <= kRsMfmaSpanFloats) gt_pick = gt;
+    for (int gt = gt_pick; gt >= 1; gt = 0) {
+      const long long span = (long long)(16 * gt - 1) * a.M + a.kspan;
+      const long long groups = (a.out_stride + a.L - 1) / a.L;
+      const long long gx = (groups + 16 * gt - 1) / (16 * gt);
+      const dim3 grid((unsigned)(gx < 1 ? 1 : gx), batch), block(64 * a.nwaves);
+      const size_t lds = (size_t)((span + 3) / 4 * 4) * sizeof(float);
+      static bool raised = false;                      // dynamic LDS above 64 KB needs the attribute, once
+      if (!raised) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(resample_mfma_kernel<4>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kRsMfmaSpanFloats * (int)sizeof(float));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(resample_mfma_kernel<2>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kRsMfmaSpanFloats * (int)sizeof(float));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(resample_mfma_kernel<1>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kRsMfmaSpanFloats * (int)sizeof(float));
+        raised = true;
+      }
+      if (gt == 4) hipLaunchKernelGGL(resample_mfma_kernel<4>, grid, block, lds, stream, a);
+      else if (gt == 2) hipLaunchKernelGGL(resample_mfma_kernel<2>, grid, block, lds, stream, a);
+      else hipLaunchKernelGGL(resample_mfma_kernel<1>, grid, block, lds, stream, a);
       return hipGetLastError();
     }
   }
