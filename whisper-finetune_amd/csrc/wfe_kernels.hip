@@ -2347,11 +2347,15 @@ __global__ __launch_bounds__(256) void resample_decimate_kernel(const ResampleAr
 // span (lane (g, k) reads xs[g M + c + k]: one ds_read per MFMA, immediate offsets).  Products with T's zeros add
 // exact zeros; every output still sums its taps in ascending order, in float32 (the order INSIDE one 4-wide
 // k-step is the matrix core's).
-template <int GT>
+// PAD (M a multiple of 8, e.g. 16 -> 44.1 kHz with M = 160): the 16 windows of a k-step would start a multiple of
+// 8 floats apart and meet in 4 or fewer LDS banks, so the span is stored with 4 extra floats per M (span index i
+// at i + 4 (i / M): window stride M + 4, 4 x odd); a k-step's 4 columns never cross a multiple of M, so its
+// extra offset is one wave-uniform number.
+template <int GT, bool PAD>
 __global__ __launch_bounds__(1024) void resample_mfma_kernel(const ResampleArgs a) {
   extern __shared__ __attribute__((aligned(16))) float xs_dyn[];
   float* xs = xs_dyn;
-  constexpr int G = 16 * GT;
+  constexpr int G = 16 * GT, P = PAD ? 4 : 0;
   const int tid = threadIdx.x, b = blockIdx.y, L = a.L, M = a.M;
   const int nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
   const long long g0 = (long long)blockIdx.x * G;
@@ -2387,7 +2391,10 @@ __global__ __launch_bounds__(1024) void resample_mfma_kernel(const ResampleArgs 
       for (int u = 0; u < 4; ++u) X[u] = buf_f32x4(rx, (v0 + nthreads * u) * 16);
 #pragma unroll
       for (int u = 0; u < 4; ++u)
-        if (v0 + nthreads * u < nvec) reinterpret_cast<f32x4*>(xs)[v0 + nthreads * u] = X[u];
+        if (v0 + nthreads * u < nvec) {
+          const int v = v0 + nthreads * u;
+          reinterpret_cast<f32x4*>(xs)[PAD ? v + (4 * v) / M : v] = X[u];     // (M % 4 == 0: a quad stays inside one M)
+        }
     }
   } else {
     for (int i0 = tid; i0 < span; i0 += nthreads * 8) {  // 8 loads in flight per thread, branch-free (Source::gather)
@@ -2401,7 +2408,10 @@ __global__ __launch_bounds__(1024) void resample_mfma_kernel(const ResampleArgs 
       src.gather<8>(idx, len_in, v);
 #pragma unroll
       for (int u = 0; u < 8; ++u)
-        if (i0 + nthreads * u < span) xs[i0 + nthreads * u] = v[u];
+        if (i0 + nthreads * u < span) {
+          const int i = i0 + nthreads * u;
+          xs[PAD ? i + 4 * (i / M) : i] = v[u];
+        }
     }
   }
   __syncthreads();
@@ -2420,7 +2430,8 @@ __global__ __launch_bounds__(1024) void resample_mfma_kernel(const ResampleArgs 
     const f32x4* __restrict__ fp = frag + (long long)foff * 64 + lane;
     const float* xb[GT];
 #pragma unroll
-    for (int gt = 0; gt < GT; ++gt) xb[gt] = xs + group_of(gt) * M + (lane >> 4) + 4 * kb_lo;
+    for (int gt = 0; gt < GT; ++gt) xb[gt] = xs + group_of(gt) * (M + P) + (lane >> 4) + (PAD ? 0 : 4 * kb_lo);
+    int col = 4 * kb_lo, rem = col % M, cpad = col + P * (col / M);   // PAD: column of the k-step, col mod M, its LDS offset
     f32x4 acc[GT];
 #pragma unroll
     for (int gt = 0; gt < GT; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -2428,10 +2439,16 @@ __global__ __launch_bounds__(1024) void resample_mfma_kernel(const ResampleArgs 
     for (int q = 0; q < nq; ++q) {
       const f32x4 An = fp[(q + 1 < nq ? q + 1 : q) * 64];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
 #pragma unroll
         for (int gt = 0; gt < GT; ++gt)
-          acc[gt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i], xb[gt][16 * q + 4 * i], acc[gt], 0, 0, 0);
+          acc[gt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i], xb[gt][PAD ? cpad : 16 * q + 4 * i], acc[gt], 0, 0, 0);
+        if (PAD) {
+          rem += 4;
+          cpad += 4;
+          if (rem >= M) rem -= M, cpad += P;
+        }
+      }
       A = An;
     }
 #pragma unroll
@@ -2741,30 +2758,34 @@ hipError_t launch_resample(const ResampleArgs& a, int batch, hipStream_t stream)
     // many phases: the GEMM form
     // groups of L outputs per workgroup: 64, 32 or 16 -- the most whose LDS span leaves room for two workgroups
     // per CU (one stages while the other multiplies), else the most that fit at all
+    const int span_pad = (a.M % 8 == 0 && !(a.tune & 64)) ? 4 : 0;   // resample_mfma_kernel<.., PAD> (WFE_TUNE & 64: without)
+    auto span_of = [&](int gt) {
+      const long long plain = (long long)(16 * gt - 1) * a.M + a.kspan;
+      return plain + span_pad * ((plain - 1) / a.M) + 8;   // (+ 8: the last staged quad may reach into the next M)
+    };
     int gt_pick = 0;
     for (int gt = 4; gt >= 1 && !gt_pick; gt >>= 1)
-      if ((long long)(16 * gt - 1) * a.M + a.kspan <= kRsMfmaSpanFloats / 2 + ((a.tune & 32) ? kRsMfmaSpanFloats : 0)) gt_pick = gt;
+      if (span_of(gt) <= kRsMfmaSpanFloats / 2 + ((a.tune & 32) ? kRsMfmaSpanFloats : 0)) gt_pick = gt;
     for (int gt = 4; gt >= 1 && !gt_pick; gt >>= 1)
-      if ((long long)(16 * gt - 1) * a.M + a.kspan <= kRsMfmaSpanFloats) gt_pick = gt;
+      if (span_of(gt) <= kRsMfmaSpanFloats) gt_pick = gt;
     for (int gt = gt_pick; gt >= 1; gt = 0) {
-      const long long span = (long long)(16 * gt - 1) * a.M + a.kspan;
+      const long long span = span_of(gt);
       const long long groups = (a.out_stride + a.L - 1) / a.L;
       const long long gx = (groups + 16 * gt - 1) / (16 * gt);
       const dim3 grid((unsigned)(gx < 1 ? 1 : gx), batch), block(64 * a.nwaves);
       const size_t lds = (size_t)((span + 3) / 4 * 4) * sizeof(float);
-      static bool raised = false;                      // dynamic LDS above 64 KB needs the attribute, once
-      if (!raised) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(resample_mfma_kernel<4>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kRsMfmaSpanFloats * (int)sizeof(float));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(resample_mfma_kernel<2>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kRsMfmaSpanFloats * (int)sizeof(float));
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(resample_mfma_kernel<1>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, kRsMfmaSpanFloats * (int)sizeof(float));
-        raised = true;
+      using Kernel = void (*)(const ResampleArgs);
+      const bool pad = span_pad != 0;
+      const Kernel kernel = gt == 4 ? (pad ? resample_mfma_kernel<4, true> : resample_mfma_kernel<4, false>)
+                          : gt == 2 ? (pad ? resample_mfma_kernel<2, true> : resample_mfma_kernel<2, false>)
+                                    : (pad ? resample_mfma_kernel<1, true> : resample_mfma_kernel<1, false>);
+      static bool raised[5][2];                        // dynamic LDS above 64 KB needs the attribute, once per kernel
+      if (!raised[gt][pad]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  kRsMfmaSpanFloats * (int)sizeof(float));
+        raised[gt][pad] = true;
       }
-      if (gt == 4) hipLaunchKernelGGL(resample_mfma_kernel<4>, grid, block, lds, stream, a);
-      else if (gt == 2) hipLaunchKernelGGL(resample_mfma_kernel<2>, grid, block, lds, stream, a);
-      else hipLaunchKernelGGL(resample_mfma_kernel<1>, grid, block, lds, stream, a);
+      hipLaunchKernelGGL(kernel, grid, block, lds, stream, a);
       return hipGetLastError();
     }
   }
