@@ -100,13 +100,17 @@ def test_resample_argument_errors(fe):
 @pytest.mark.parametrize("orig,target", [(44100, 16000), (48000, 16000), (8000, 16000), (22050, 16000),
                                          (16000, 44100), (24000, 16000), (32000, 16000), (96000, 16000), (64000, 16000),
                                          (12000, 16000), (16000, 8000), (16000, 32000), (16000, 24000)])
-def test_phase_sharing_kernel_matches_round1_kernel(monkeypatch, orig, target):
-    """resample_phase_kernel (a thread's outputs share one filter phase) accumulates every output's taps in the
-    same order as resample_kernel (WFE_TUNE=4 keeps that one): identical bits, on ragged lengths including an
-    utterance shorter than the filter and an empty one."""
+def test_round2_kernels_match_round1_kernel(monkeypatch, orig, target):
+    """Round 2's resamplers -- resample_mfma_kernel (the default: the banded filter matrix on the matrix cores) and,
+    with WFE_TUNE=16, resample_decimate_kernel (few phases, sliding window) / resample_phase_kernel (a thread's
+    outputs share one filter phase) -- accumulate every output's taps in the same order as round 1's
+    resample_kernel (WFE_TUNE=4 keeps that one): identical bits, on ragged lengths including an utterance shorter
+    than the filter and an empty one."""
     from wfe_amd.frontend import HipFrontEnd
     monkeypatch.delenv("WFE_TUNE", raising=False)
     fe_new = HipFrontEnd(n_mel=80, device=0)
+    monkeypatch.setenv("WFE_TUNE", "16")
+    fe_valu = HipFrontEnd(n_mel=80, device=0)
     monkeypatch.setenv("WFE_TUNE", "4")
     fe_old = HipFrontEnd(n_mel=80, device=0)
     n = 3 * orig
@@ -114,8 +118,28 @@ def test_phase_sharing_kernel_matches_round1_kernel(monkeypatch, orig, target):
     x = 0.1 * torch.randn((5, n), generator=g, device="cuda")
     host = [n, n // 3, 7, 0, 2 * orig + 13]
     lens = torch.tensor(host, dtype=torch.int32, device="cuda")
-    a = fe_new.resample(x, lens, orig, target, host_lengths=host)
-    b = fe_old.resample(x, lens, orig, target, host_lengths=host)
-    a, b = (a[0], b[0]) if isinstance(a, tuple) else (a, b)
+    outs = []
+    for fe_ in (fe_new, fe_valu, fe_old):
+        r = fe_.resample(x, lens, orig, target, host_lengths=host)
+        outs.append(r[0] if isinstance(r, tuple) else r)
     torch.cuda.synchronize()
-    assert torch.equal(a, b)
+    assert torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[1], outs[2])
+
+
+def test_matrix_core_kernel_pcm16_stereo_ragged_matches_round1_kernel(monkeypatch):
+    """The same identity on the staging path that converts interleaved 16-bit PCM (the gather form) with ragged
+    offsets, 44.1 kHz stereo -> 16 kHz."""
+    from wfe_amd.frontend import HipFrontEnd
+    monkeypatch.delenv("WFE_TUNE", raising=False)
+    fe_new = HipFrontEnd(n_mel=80, device=0)
+    monkeypatch.setenv("WFE_TUNE", "4")
+    fe_old = HipFrontEnd(n_mel=80, device=0)
+    rng = np.random.default_rng(8)
+    pcm = rng.integers(-20000, 20000, size=(3, 70001, 2), dtype=np.int16)
+    dense = torch.from_numpy(pcm.reshape(3, -1)).cuda()
+    lens = torch.tensor([70001, 33333, 5], dtype=torch.int32, device="cuda")
+    a = fe_new.resample(dense, lens, 44100, 16000, channels=2)
+    b = fe_old.resample(dense, lens, 44100, 16000, channels=2)
+    torch.cuda.synchronize()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])

@@ -46,7 +46,7 @@ struct wfe_context {
     // the same filter in the order resample_mfma_kernel reads it (ratios with >= 64 phases), else null
     float* d_frag = nullptr;
     int* d_meta = nullptr;
-    int ptiles = 0, kspan = 0, nwaves = 0;
+    int ptiles = 0, kspan = 0, nwaves = 0, group = 1;
   };
   std::map<std::pair<int, int>, RsTable> rs_tables;   // (in_rate, out_rate) -> filter on the device
   float* d_tile_stats = nullptr;            // per-tile minima / maxima of kernel 1, grows on demand
@@ -561,8 +561,11 @@ int wfe_reverb(wfe_handle h, const float* wav, const int64_t* offsets, const int
 // The polyphase filter [taps][L] as the A operand of resample_mfma_kernel: T[p][c] = table[c - floor(p M / L)][(p M) mod L]
 // (zero outside the taps), per tile of 16 phases only the k-steps (4 columns) its band touches, rounded to quads;
 // lane l of a fragment holds row l % 16, column l / 16 of the k-step, 4 consecutive k-steps per float4.
-static void build_resample_fragments(const std::vector<float>& table, int L, int M, int taps, std::vector<float>& frag,
-                                     std::vector<int>& meta, int& kspan) {
+// r > 1: groups of r L outputs (ratios with few phases: the same matrix, r times as tall, rows p >= L repeat the
+// columns p mod L shifted by whole input steps).
+static void build_resample_fragments(const std::vector<float>& table, int L0, int M0, int r, int taps,
+                                     std::vector<float>& frag, std::vector<int>& meta, int& kspan) {
+  const int L = L0 * r, M = M0 * r;
   const int ptiles = (L + 15) / 16;
   meta.assign(3 * (size_t)ptiles, 0);
   frag.clear();
@@ -584,7 +587,7 @@ static void build_resample_fragments(const std::vector<float>& table, int L, int
           float v = 0.f;
           if (p < L) {
             const long long j = c - (long long)p * M / L;
-            if (j >= 0 && j < taps) v = table[(size_t)j * L + (size_t)((long long)p * M % L)];
+            if (j >= 0 && j < taps) v = table[(size_t)j * L0 + (size_t)((long long)p * M0 % L0)];
           }
           frag[((size_t)(foff + q) * 64 + lane) * 4 + i] = v;
         }
@@ -626,18 +629,19 @@ int wfe_resample(wfe_handle h, const void* in, int32_t pcm_channels, const int64
       (void)hipFree(t.d);
       return fail(h, WFE_ERR_HIP, "resample table upload: %s", hipGetErrorString(e));
     }
-    if (t.L >= 64) {                                   // the GEMM form: the table as matrix-core fragments
+    {                                                  // the GEMM form: the table as matrix-core fragments
       std::vector<float> frag;
       std::vector<int> meta;
-      build_resample_fragments(host, t.L, t.M, t.taps, frag, meta, t.kspan);
-      t.ptiles = (t.L + 15) / 16;
+      t.group = t.L >= 64 ? 1 : (160 + t.L - 1) / t.L;  // few phases: groups of about 160 outputs
+      build_resample_fragments(host, t.L, t.M, t.group, t.taps, frag, meta, t.kspan);
+      t.ptiles = (t.L * t.group + 15) / 16;
       int best = 1 << 30;
       for (int nw = 8; nw <= 16; ++nw) {               // waves per workgroup: the least idle tile slots, then the most waves
         const int waste = (t.ptiles + nw - 1) / nw * nw - t.ptiles;
         if (waste <= best) best = waste, t.nwaves = nw;
       }
       if (t.ptiles < 8) t.nwaves = t.ptiles;
-      if (15LL * t.M + t.kspan <= wfe::kRsMfmaSpanFloats && frag.size() <= (64u << 20)) {
+      if (15LL * t.M * t.group + t.kspan + 1024 <= wfe::kRsMfmaSpanFloats && frag.size() <= (64u << 20)) {
         hipError_t e1 = hipMalloc(&t.d_frag, frag.size() * sizeof(float));
         hipError_t e2 = e1 == hipSuccess ? hipMalloc(&t.d_meta, meta.size() * sizeof(int)) : e1;
         if (e2 == hipSuccess) e2 = hipMemcpy(t.d_frag, frag.data(), frag.size() * sizeof(float), hipMemcpyHostToDevice);
@@ -688,6 +692,7 @@ int wfe_resample(wfe_handle h, const void* in, int32_t pcm_channels, const int64
     a.ptiles = t.ptiles;
     a.kspan = t.kspan;
     a.nwaves = t.nwaves;
+    a.frag_group = t.group;
     HIP_TRY(h, wfe::launch_resample(a, s.count, stream));
   }
   return WFE_OK;

@@ -108,6 +108,7 @@ struct ResampleArgs {
   const float* frag;             // per tile of 16 phases: [quads of k-steps][64 lanes][4] floats
   const int* frag_meta;          // per tile: first k-step, quads of k-steps, offset into frag (in 64 x float4)
   int ptiles, kspan, nwaves;     // tiles of 16 phases; LDS columns the widest tile reaches; waves per workgroup
+  int frag_group;                // the fragments describe groups of frag_group * L outputs (frag_group * M inputs)
 };
 hipError_t launch_resample(const ResampleArgs& a, int batch, hipStream_t stream);
 

@@ -2734,9 +2734,52 @@ hipError_t launch_reverb(const ReverbArgs& a, int batch, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// resample_mfma_kernel, when the ratio's fragments exist and a span fits: true if launched
+static bool launch_resample_mfma(const ResampleArgs& a0, int batch, hipStream_t stream) {
+  if (!a0.frag) return false;
+  ResampleArgs a = a0;
+  a.L = a0.L * a0.frag_group;                          // the kernel's group: frag_group * L outputs from frag_group * M inputs
+  a.M = a0.M * a0.frag_group;
+  // groups of L outputs per workgroup: 64, 32 or 16 -- the most whose LDS span leaves room for two workgroups
+  // per CU (one stages while the other multiplies), else the most that fit at all
+  const int span_pad = (a.M % 8 == 0 && !(a.tune & 64)) ? 4 : 0;   // resample_mfma_kernel<.., PAD> (WFE_TUNE & 64: without)
+  auto span_of = [&](int gt) {
+    const long long plain = (long long)(16 * gt - 1) * a.M + a.kspan;
+    return plain + span_pad * ((plain - 1) / a.M) + 8;   // (+ 8: the last staged quad may reach into the next M)
+  };
+  int gt_pick = 0;
+  for (int gt = 4; gt >= 1 && !gt_pick; gt >>= 1)
+    if (span_of(gt) <= kRsMfmaSpanFloats / 2 + ((a.tune & 32) ? kRsMfmaSpanFloats : 0)) gt_pick = gt;
+  for (int gt = 4; gt >= 1 && !gt_pick; gt >>= 1)
+    if (span_of(gt) <= kRsMfmaSpanFloats) gt_pick = gt;
+  if (gt_pick) {
+    const int gt = gt_pick;
+    const long long span = span_of(gt);
+    const long long groups = (a.out_stride + a.L - 1) / a.L;
+    const long long gx = (groups + 16 * gt - 1) / (16 * gt);
+    const dim3 grid((unsigned)(gx < 1 ? 1 : gx), batch), block(64 * a.nwaves);
+    const size_t lds = (size_t)((span + 3) / 4 * 4) * sizeof(float);
+    using Kernel = void (*)(const ResampleArgs);
+    const bool pad = span_pad != 0;
+    const Kernel kernel = gt == 4 ? (pad ? resample_mfma_kernel<4, true> : resample_mfma_kernel<4, false>)
+                        : gt == 2 ? (pad ? resample_mfma_kernel<2, true> : resample_mfma_kernel<2, false>)
+                                  : (pad ? resample_mfma_kernel<1, true> : resample_mfma_kernel<1, false>);
+    // dynamic LDS above 64 KB needs the attribute; it is a property of the kernel ON the current device, so it is
+    // set per launch (a host-side table lookup) rather than remembered per process
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            kRsMfmaSpanFloats * (int)sizeof(float)) != hipSuccess)
+      return false;
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, a);
+    return true;
+  }
+  return false;
+}
+
 hipError_t launch_resample(const ResampleArgs& a, int batch, hipStream_t stream) {
   // outputs S apart share a filter phase when L | S: S = the smallest multiple of L that fills 4 waves
   const int S = a.L >= 256 ? a.L : (256 + a.L - 1) / a.L * a.L;
+  // first choice: the matrix-core kernel (WFE_TUNE & 16: without it, for A/B and to test the kernels below)
+  if (!(a.tune & (4 | 16)) && launch_resample_mfma(a, batch, stream)) return hipGetLastError();
   if (a.L <= 4 && !(a.tune & 4) && (a.M == 1 || a.M == 2 || a.M == 3 || a.M == 4 || a.M == 6)) {
     // few phases: the sliding-window kernel, one grid layer per phase, when its span and taps fit
     const int W = 6 * a.M + 1, taps_p = (a.taps + W - 1) / W * W;
@@ -2751,41 +2794,6 @@ hipError_t launch_resample(const ResampleArgs& a, int batch, hipStream_t stream)
         case 4: hipLaunchKernelGGL(resample_decimate_kernel<4>, grid, dim3(256), 0, stream, a); break;
         default: hipLaunchKernelGGL(resample_decimate_kernel<6>, grid, dim3(256), 0, stream, a); break;
       }
-      return hipGetLastError();
-    }
-  }
-  if (a.frag && !(a.tune & (4 | 16))) {               // (WFE_TUNE & 16: without the matrix-core kernel, for A/B)
-    // many phases: the GEMM form
-    // groups of L outputs per workgroup: 64, 32 or 16 -- the most whose LDS span leaves room for two workgroups
-    // per CU (one stages while the other multiplies), else the most that fit at all
-    const int span_pad = (a.M % 8 == 0 && !(a.tune & 64)) ? 4 : 0;   // resample_mfma_kernel<.., PAD> (WFE_TUNE & 64: without)
-    auto span_of = [&](int gt) {
-      const long long plain = (long long)(16 * gt - 1) * a.M + a.kspan;
-      return plain + span_pad * ((plain - 1) / a.M) + 8;   // (+ 8: the last staged quad may reach into the next M)
-    };
-    int gt_pick = 0;
-    for (int gt = 4; gt >= 1 && !gt_pick; gt >>= 1)
-      if (span_of(gt) <= kRsMfmaSpanFloats / 2 + ((a.tune & 32) ? kRsMfmaSpanFloats : 0)) gt_pick = gt;
-    for (int gt = 4; gt >= 1 && !gt_pick; gt >>= 1)
-      if (span_of(gt) <= kRsMfmaSpanFloats) gt_pick = gt;
-    for (int gt = gt_pick; gt >= 1; gt = 0) {
-      const long long span = span_of(gt);
-      const long long groups = (a.out_stride + a.L - 1) / a.L;
-      const long long gx = (groups + 16 * gt - 1) / (16 * gt);
-      const dim3 grid((unsigned)(gx < 1 ? 1 : gx), batch), block(64 * a.nwaves);
-      const size_t lds = (size_t)((span + 3) / 4 * 4) * sizeof(float);
-      using Kernel = void (*)(const ResampleArgs);
-      const bool pad = span_pad != 0;
-      const Kernel kernel = gt == 4 ? (pad ? resample_mfma_kernel<4, true> : resample_mfma_kernel<4, false>)
-                          : gt == 2 ? (pad ? resample_mfma_kernel<2, true> : resample_mfma_kernel<2, false>)
-                                    : (pad ? resample_mfma_kernel<1, true> : resample_mfma_kernel<1, false>);
-      static bool raised[5][2];                        // dynamic LDS above 64 KB needs the attribute, once per kernel
-      if (!raised[gt][pad]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  kRsMfmaSpanFloats * (int)sizeof(float));
-        raised[gt][pad] = true;
-      }
-      hipLaunchKernelGGL(kernel, grid, block, lds, stream, a);
       return hipGetLastError();
     }
   }
