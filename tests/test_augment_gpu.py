@@ -111,6 +111,40 @@ def test_full_chain_matches_reference(fe, golden_augment):
         assert not got[s, len(w):].any()
 
 
+def test_noise_gains_do_not_depend_on_buffer_alignment(fe):
+    """the float64 sums behind the NOISE gains / AFFINE statistics take the same partition and
+    order wherever the utterance starts in the caller's buffer (raw C-ABI callers need not align
+    their offsets to 16 bytes): the augmented waveform is bit-identical for offsets 0..3 mod 4."""
+    from wfe_amd import _lib
+    from wfe_amd.frontend import NoiseBank
+    bank = [cases.noise_clip(0, 0.4), cases.noise_clip(1, 2.5)]
+    nb = NoiseBank(bank, fe.device)
+    x = [cases.bench_clip(10 + i, 30011 + 977 * i) for i in range(4)]
+    plans = [[(_lib.AUG_NOISE, i % 2, 0, 20 + i, 0.0)] for i in range(4)] + \
+            [[(_lib.AUG_AFFINE, 0, 0, 0, 0.0)] for _ in range(4)]
+    waves = x + x
+    outs = []
+    for shift in (0, 1, 2, 3):
+        off, pos = [], shift
+        for w in waves:
+            off.append(pos)
+            pos += (len(w) + 3) // 4 * 4                     # every utterance at `shift` mod 4 floats
+        flat = np.zeros(pos + 8, np.float32)
+        for o, w in zip(off, waves):
+            flat[o:o + len(w)] = w
+        d_flat = torch.from_numpy(flat).to(fe.device)
+        d_off = torch.tensor(off, dtype=torch.int64, device=fe.device)
+        d_len = torch.tensor([len(w) for w in waves], dtype=torch.int32, device=fe.device)
+        wav, wl = fe.augment_waveform(d_flat, d_len, plans, nb, n_samples=36000, offsets=d_off)
+        mel = fe.augment_logmel(d_flat, d_len, plans, nb, n_samples=36000, offsets=d_off)
+        torch.cuda.synchronize()
+        outs.append((wav.cpu().numpy(), mel.cpu().numpy()))
+    for shift in (1, 2, 3):
+        assert np.array_equal(outs[0][0], outs[shift][0]), shift
+        assert np.array_equal(outs[0][1], outs[shift][1]), shift
+    assert np.abs(outs[0][0]).max() > 0
+
+
 def test_truncation_and_fused_logmel(fe):
     """Augmented waveform -> pad/trim -> log-mel in ONE fused launch equals the CPU
     oracle run on the oracle-augmented waveform (config 3 shape, 30 s clips)."""

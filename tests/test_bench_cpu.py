@@ -54,3 +54,32 @@ def test_missing_devices_and_mismatched_world_fail_loudly():
     assert r.returncode != 0 and "they must agree" in (r.stderr + r.stdout)
     r = _run(["--gpus", "0"])
     assert r.returncode != 0
+
+
+def test_self_launch_parent_never_loads_torch_or_hip(tmp_path):
+    """The parent of a self-launched multi-rank run must not be able to reach hipInit before it spawns
+    the ranks: bench.py's top level imports the standard library only, devices are
+    counted from sysfs.  The parent reports what it had mapped when it spawned."""
+    report = tmp_path / "maps.json"
+    r = _run(["--gpus", "2", "--shard-clips", "64", "--batch", "32", "--stub-transform"],
+             {"WFE_BENCH_PARENT_MAPS": str(report)})
+    assert r.returncode == 0, r.stderr[-2000:]
+    seen = json.loads(report.read_text())
+    assert seen == {"loaded": [], "torch_imported": False}
+    # and importing the module alone pulls in neither torch nor numpy
+    code = "import sys; sys.path.insert(0, %r); import bench; print('torch' in sys.modules, 'numpy' in sys.modules)" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert out.stdout.split() == ["False", "False"], out.stdout + out.stderr
+
+
+def test_visible_gpu_count_reads_env_lists_without_hip(monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    base = bench.visible_gpu_count()                         # None in a container without /sys/class/kfd
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
+    n = bench.visible_gpu_count()
+    assert n == (3 if base is None else min(base, 3))
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpu_count() == 0

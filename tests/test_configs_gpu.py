@@ -68,7 +68,8 @@ def _read_wav(path):
         return np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").astype(np.float32) / 32768.0
 
 
-def test_config5_collator_feeds_a_whisper_training_step(tmp_path):
+@pytest.mark.parametrize("strip_sot", [False, True])
+def test_config5_collator_feeds_a_whisper_training_step(tmp_path, strip_sot):
     from transformers import WhisperConfig, WhisperForConditionalGeneration
     from wfe_amd import data as wd
     recs = []
@@ -80,7 +81,8 @@ def test_config5_collator_feeds_a_whisper_training_step(tmp_path):
     mf.write_text("\n".join(json.dumps(r) for r in recs))
     proc = stubs.StubProcessor(80)
     ds = wd.CustomDataset(str(mf), proc, language="en")
-    coll = wd.DataCollatorSpeechSeq2SeqWithPadding(processor=proc)
+    # default = the upstream collator (labels keep <|startoftranscript|>); strip_sot=True = the opt-in HF recipe
+    coll = wd.DataCollatorSpeechSeq2SeqWithPadding(processor=proc, strip_sot=strip_sot)
     loader = torch.utils.data.DataLoader(ds, batch_size=3, shuffle=False, num_workers=0, collate_fn=coll)
 
     torch.manual_seed(0)
@@ -96,15 +98,16 @@ def test_config5_collator_feeds_a_whisper_training_step(tmp_path):
         assert feats.shape == (3, 80, 3000) and feats.dtype == torch.float32 and labels.dtype == torch.int64
         assert np.abs(feats.numpy() - want[3 * k:3 * k + 3]).max() <= TOL
         rows = [ds[3 * k + j]["labels"] for j in range(3)]
-        width = max(len(r) for r in rows) - 1
-        for j, r in enumerate(rows):                                 # start token dropped, -100 behind the row
+        drop = 1 if strip_sot else 0
+        width = max(len(r) for r in rows) - drop
+        for j, r in enumerate(rows):                                 # -100 behind the row
             assert r[0] == stubs.SOT
-            assert labels[j].tolist() == r[1:] + [-100] * (width - (len(r) - 1))
+            assert labels[j].tolist() == r[drop:] + [-100] * (width - (len(r) - drop))
         out = model(input_features=feats.to("cuda"), labels=labels.to("cuda"))
         # what the decoder was fed: the labels shifted right behind ONE start token
         from transformers.models.whisper.modeling_whisper import shift_tokens_right
         dec = shift_tokens_right(labels, cfg.pad_token_id, cfg.decoder_start_token_id)
-        assert (dec[:, 0] == stubs.SOT).all() and not (dec[:, 1] == stubs.SOT).any()
+        assert (dec[:, 0] == stubs.SOT).all() and bool((dec[:, 1] == stubs.SOT).all()) == (not strip_sot)
         assert torch.isfinite(out.loss)
         out.loss.backward()
         losses.append(float(out.loss))

@@ -181,17 +181,22 @@ def test_collator_contract_on_precomputed_features():
         {"input_features": None, "labels": None, "id": "error_1"},
         {"input_features": torch.zeros((1, 80, 3000)), "labels": [stubs.SOT, 7, stubs.EOT], "id": "c"},
     ]
-    for cls, strip, ids in ((wd.DataCollatorSpeechSeq2SeqWithPadding, (stubs.EOT, stubs.SOT), False),
-                            (wd.DataCollatorSpeechSeq2SeqWithPaddingforEval, (), True)):
-        got = cls(processor=proc)(items)
+    for cls, strip, ids, kw in ((wd.DataCollatorSpeechSeq2SeqWithPadding, (stubs.EOT,), False, {}),
+                                (wd.DataCollatorSpeechSeq2SeqWithPadding, (stubs.EOT, stubs.SOT), False, {"strip_sot": True}),
+                                (wd.DataCollatorSpeechSeq2SeqWithPaddingforEval, (), True, {})):
+        got = cls(processor=proc, **kw)(items)
         want = oc.collate(items, 80, 3000, strip_tokens=strip, with_ids=ids)
         assert got["input_features"].dtype == torch.float32 and got["labels"].dtype == torch.int64
         assert np.array_equal(got["input_features"].numpy(), want["input_features"])
         assert np.array_equal(got["labels"].numpy(), want["labels"])
         assert got.get("id") == want.get("id")
     assert got["labels"][1].tolist() == [stubs.SOT, 7, stubs.EOT, -100]          # evaluation.py:106,111
-    # training: the shared <|startoftranscript|> is dropped (the model prepends it again), padding is -100
+    # training, upstream default: only bos_token_id (= <|endoftext|> for Whisper) is ever stripped, so
+    # the labels START WITH <|startoftranscript|>; padding is -100
     train = wd.DataCollatorSpeechSeq2SeqWithPadding(processor=proc)(items)["labels"].tolist()
+    assert train == [[stubs.SOT, 5, 6, stubs.EOT], [stubs.SOT, 7, stubs.EOT, -100]]
+    # the opt-in deviation (strip_sot=True or WFE_STRIP_SOT=1): the shared <|startoftranscript|> is dropped
+    train = wd.DataCollatorSpeechSeq2SeqWithPadding(processor=proc, strip_sot=True)(items)["labels"].tolist()
     assert train == [[5, 6, stubs.EOT], [7, stubs.EOT, -100]]
     # a shared leading BOS is stripped by the training collator only
     bos_items = [{"input_features": np.zeros((1, 80, 3000), np.float32), "labels": [stubs.EOT, 1, 2], "id": "x"}]

@@ -76,8 +76,8 @@ def test_dataset_collator_end_to_end(tmp_path, n_mel):
     print("end-to-end max-abs-err per utterance:", err)
     assert (err <= 1e-4).all(), err
     lab = batches[0]["labels"]
-    # training collator: the shared <|startoftranscript|> is dropped (the model's shift-right re-adds it)
-    assert lab[0].tolist()[:3] == [stubs.EN, stubs.TRANSCRIBE, stubs.NOTIMESTAMPS]
+    # training collator, upstream default: the labels keep their <|startoftranscript|>
+    assert lab[0].tolist()[:4] == [stubs.SOT, stubs.EN, stubs.TRANSCRIBE, stubs.NOTIMESTAMPS]
 
 
 def test_specaug_and_eval_collator(tmp_path):

@@ -49,7 +49,7 @@ constexpr int kStampRow = 16;   // 0..5 phase boundaries, 6 hardware id, 7 k-loo
     if (a.stamps && lane == 0) {                                                       \
       unsigned long long t_;                                                           \
       asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");       \
-      a.stamps[((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + blockIdx.x) * 4 + wave) * kStampRow + (i)] = t_; \
+      a.stamps[((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + tx) * 4 + wave) * kStampRow + (i)] = t_; \
     }                                                                                  \
   } while (0)
 #else
@@ -74,6 +74,8 @@ using f32x2 = __attribute__((ext_vector_type(2))) float;
 // two consecutive floats at any 4-byte boundary: one global_load_dwordx2 (the memory pipe
 // spends ~16 cycles per wave on ANY per-lane-addressed load, so fewer, wider loads)
 typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+// four consecutive floats at any 4-byte boundary: one global_load_dwordx4 (dword alignment is all the memory pipe asks)
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
 // The 7 twiddles (one per bin tile) a lane needs per GEMM and k-step.  The table
 // stores 8 (two float4) but the 8th is padding: it is fetched as float4 + float3
@@ -1873,10 +1875,12 @@ __global__ __launch_bounds__(256) void resolve_partial_kernel(const FrontArgs a,
   const int per = (L + kResolveParts - 1) / kResolveParts;
   const int lo = part * per, hi = (lo + per < L) ? lo + per : L;
   double s1 = 0.0, s2 = 0.0;
-  if (k0 == 0 && src.w && ((reinterpret_cast<uintptr_t>(src.w) & 15u) == 0)) {
+  if (k0 == 0 && src.w) {
     // the signal entering the chain's first op is the source itself (the shipped order starts with NOISE):
-    // 16-byte loads, four rows in flight per thread
-    const f32x4* __restrict__ w4 = reinterpret_cast<const f32x4*>(src.w);
+    // 16-byte loads, four rows in flight per thread.  The loads ask for dword alignment only, so the partition
+    // and the order of the sums -- and with them the last bit of the gains -- do not depend on where the
+    // utterance starts in the caller's buffer (tests: unaligned offsets).
+    const f32x4u* __restrict__ w4 = reinterpret_cast<const f32x4u*>(src.w);
     const int lo4 = (lo + 3) >> 2, hi4 = hi >> 2;                 // whole float4s inside [lo, hi)
     auto take = [&](float x) {
       s1 += (double)x;
@@ -2767,8 +2771,10 @@ static bool launch_resample_mfma(const ResampleArgs& a0, int batch, hipStream_t 
     // dynamic LDS above 64 KB needs the attribute; it is a property of the kernel ON the current device, so it is
     // set per launch (a host-side table lookup) rather than remembered per process
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            kRsMfmaSpanFloats * (int)sizeof(float)) != hipSuccess)
+                            kRsMfmaSpanFloats * (int)sizeof(float)) != hipSuccess) {
+      (void)hipGetLastError();                           // the fallback's launch check must not see this failure
       return false;
+    }
     hipLaunchKernelGGL(kernel, grid, block, lds, stream, a);
     return true;
   }

@@ -472,9 +472,8 @@ def _pad_labels(rows: List[List[int]], strip_tokens=()) -> torch.Tensor:
     out = torch.full((len(rows), width), -100, dtype=torch.int64)
     for i, r in enumerate(rows):
         out[i, :len(r)] = torch.as_tensor(r, dtype=torch.int64)
-    # Training convention (not verifiable in the reference tree): the model builds
-    # decoder_input_ids by shifting the labels right and prepending its decoder start token, so a
-    # start token shared by every row is dropped here -- otherwise the decoder would see it twice.
+    # Training convention (not verifiable in the reference tree): a token of
+    # ``strip_tokens`` that leads EVERY row is dropped (upstream: bos_token_id only).
     if width > 0 and len(rows) > 0 and any(t is not None and bool((out[:, 0] == t).all()) for t in strip_tokens):
         out = out[:, 1:]
     return out
@@ -490,9 +489,15 @@ class DataCollatorSpeechSeq2SeqWithPadding:
     with_ids = False
 
     def __init__(self, processor: Any, device=None, device_output: Optional[bool] = None, noise_clips=None,
-                 noise_rates=None, output_dtype=None):
+                 noise_rates=None, output_dtype=None, strip_sot: Optional[bool] = None):
         self.processor = processor
         self.device = device
+        # Leading-token handling of the training labels.  Default = the upstream project's collator: only a
+        # shared ``bos_token_id`` is dropped (for Whisper tokenizers that is <|endoftext|>, which never leads
+        # a row, so <|startoftranscript|> STAYS in the labels).  strip_sot=True / WFE_STRIP_SOT=1 also drops a
+        # shared <|startoftranscript|> (the HF recipe: the model's shift-right prepends it again) -- a
+        # deliberate, opt-in deviation.
+        self.strip_sot = (os.environ.get("WFE_STRIP_SOT", "0") == "1") if strip_sot is None else bool(strip_sot)
         self.device_output = (os.environ.get("WFE_DEVICE_OUTPUT", "0") == "1") if device_output is None \
             else bool(device_output)
         # input_features in the training dtype straight from the kernels (fp16=True, finetune.py:122):
@@ -512,18 +517,18 @@ class DataCollatorSpeechSeq2SeqWithPadding:
     def _strip_tokens(self):
         """Leading label tokens the training collator drops when every row starts with one of them:
         the tokenizer's ``bos_token_id`` (the check of the upstream project's collator; for Whisper
-        tokenizers that is <|endoftext|>, which never leads a label row) and
-        <|startoftranscript|>, the decoder start token the model prepends itself
-        (WhisperForConditionalGeneration shifts the labels right).  The eval collator keeps
-        the prompt: evaluation.py:106 feeds labels[:, :4] to generate()."""
+        tokenizers that is <|endoftext|>, which never leads a label row, so the labels keep their
+        <|startoftranscript|>) and, only with ``strip_sot``, <|startoftranscript|> itself.  The eval
+        collator keeps the prompt: evaluation.py:106 feeds labels[:, :4] to generate()."""
         if self.keep_prompt:
             return ()
         tok = self.processor.tokenizer
         sot = None
-        try:
-            sot = tok.get_vocab().get("<|startoftranscript|>")
-        except Exception:  # noqa: BLE001
-            pass
+        if self.strip_sot:
+            try:
+                sot = tok.get_vocab().get("<|startoftranscript|>")
+            except Exception:  # noqa: BLE001
+                pass
         return (getattr(tok, "bos_token_id", None), sot)
 
     def set_noise_clips(self, clips, rates=None, rir_clips=None, rir_rates=None):

@@ -74,17 +74,22 @@ def force_num_workers_zero(argv: list, note=sys.stderr) -> list:
     """argv of the script with ``--num_workers 0``; says why whenever it changes anything."""
     reason = ("[wfe_amd.launch] --num_workers {} -> 0: the GPU collator runs in the rank's main process (a forked "
               "DataLoader worker cannot use the GPU); host decode is threaded inside CustomDataset (WFE_DECODE_THREADS)")
+    def is_flag(name: str) -> bool:
+        # argparse (allow_abbrev) also takes the unambiguous prefixes: the reference's scripts define
+        # --num_workers and --num_train_epochs, so everything from "--num_w" on means the former
+        return len(name) >= len("--num_w") and "--num_workers".startswith(name)
+
     out, i, seen = [], 0, False
     while i < len(argv):
         a = argv[i]
-        if a == "--num_workers" and i + 1 < len(argv):
+        if is_flag(a) and i + 1 < len(argv):
             seen = True
             if argv[i + 1] != "0":
                 print(reason.format(argv[i + 1]), file=note)
-            out += [a, "0"]
+            out += ["--num_workers", "0"]
             i += 2
             continue
-        if a.startswith("--num_workers="):
+        if "=" in a and is_flag(a.split("=", 1)[0]):
             seen = True
             if a.split("=", 1)[1] != "0":
                 print(reason.format(a.split("=", 1)[1]), file=note)
