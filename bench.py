@@ -11,7 +11,7 @@ and `value` is the sum over ranks.
 
 Prints ONE JSON line on rank 0.  Besides the driver's contract it carries
   roofline      achieved = the f32 MFMA FLOPs the folded DFT + mel kernel has to issue
-                (0.297 GF per 30 s clip at 80 mel: the fold removes 3/4 of the
+                (0.243 GF per 30 s clip at 80 mel: the folds remove 4/5 of the
                 1.061 GF a plain 400x402 DFT-GEMM is priced at in SURVEY 8d; that
                 figure is reported as priced_tflops) x clips per launch / mean device
                 time of the kernel, measured with HIP events on the launch stream
@@ -70,9 +70,10 @@ def _heavy() -> None:
 
 def executed_gflop_per_clip(n_mel: int) -> float:
     """The algorithmic work of the FOLDED formulation: 47 tiles x 4 waves x
-    (4 GEMMs x 7 bin tiles x 25 k-steps = 700 DFT + 72 | 84 mel) v_mfma_f32_16x16x4_f32 of
-    2048 FLOP each.  SQ_INSTS_MFMA per launch equals this count exactly (profiles/)."""
-    return 47 * 4 * (700 + (72 if n_mel <= 80 else 84)) * 2048 / 1e9
+    (25 k-steps x (14 odd-class + 8 even-class) + 8 = 558 DFT + 72 | 84 mel) v_mfma_f32_16x16x4_f32 of
+    2048 FLOP each (round 3: the even class is folded once more; 700 DFT MFMAs before).
+    SQ_INSTS_MFMA per launch equals this count exactly (profiles/)."""
+    return 47 * 4 * (558 + (72 if n_mel <= 80 else 84)) * 2048 / 1e9
 
 
 def measured_traffic(batch: int, n_mel: int, augment: bool, lengths: str):

@@ -33,7 +33,7 @@ def _tables(n_mel):
     mask = np.zeros(14, dtype=np.uint32)
     assert lib.wfe_build_dft_table(dft.ctypes.data) == 0
     assert lib.wfe_build_mel_table(n_mel, mel.ctypes.data, mask.ctypes.data) == 0
-    return dft.reshape(25, 4, 2, 64, 4), mel.reshape(2, 7, 8, 64, 4), mask
+    return dft.reshape(25, 8, 64, 4), mel.reshape(14, 8, 64, 4), mask      # [step][quad][lane][4], [power tile][mel tile][lane][reg]
 
 
 @pytest.mark.parametrize("n_mel", [80, 128, 1, 37])
@@ -52,50 +52,99 @@ def test_mel_filters_match_oracle(n_mel, golden_logmel):
 
 
 def test_k_step_map_covers_each_n_once():
+    """wfe_layout.h dft_n_of: class 1 = the odd n over 25 k-steps; class 0 = the even n over 26 even-steps
+    (13 of n = 0 mod 4, then 13 of n = 2 mod 4), whose last step per sub-class pads with dummies n > 200."""
     lib = _lib.lib()
-    for c, want in ((0, set(range(2, 201, 2))), (1, set(range(1, 200, 2)))):
-        got = [lib.wfe_dft_n_of(c, s, kk) for s in range(25) for kk in range(4)]
-        assert len(got) == 100 and set(got) == want
-        # bank-conflict rule: k-lanes 0/1 and 2/3 differ by 16 in all but the last step
-        for s in range(24):
+    odd = [lib.wfe_dft_n_of(1, s, kk) for s in range(25) for kk in range(4)]
+    assert len(odd) == 100 and set(odd) == set(range(1, 200, 2))
+    ee = [lib.wfe_dft_n_of(0, s, kk) for s in range(13) for kk in range(4)]
+    eo = [lib.wfe_dft_n_of(0, s, kk) for s in range(13, 26) for kk in range(4)]
+    assert sorted(n for n in ee if n <= 200) == list(range(4, 201, 4))
+    assert sorted(n for n in eo if n <= 200) == list(range(2, 200, 4))
+    assert sorted(n for n in ee + eo if n > 200) == [210, 212, 214, 216]      # dummy k-lanes: zero table entries
+    # bank-conflict rule: k-lanes 0/1 and 2/3 differ by 16 (all odd steps but the last, every even-step)
+    for c, steps in ((1, range(24)), (0, range(26))):
+        for s in steps:
             assert lib.wfe_dft_n_of(c, s, 1) - lib.wfe_dft_n_of(c, s, 0) == 16
             assert lib.wfe_dft_n_of(c, s, 3) - lib.wfe_dft_n_of(c, s, 2) == 16
 
 
+def _power_bin_of(T, row):
+    """wfe_layout.h power_bin_of: U lo (bins p), U hi (200 - p), V a (100 - p), V b (100 + p)."""
+    if T < 4:
+        p = 16 * T + row
+        return p if p < 53 else -1
+    if T < 8:
+        p = 16 * (T - 4) + row
+        return 200 - p if p < 53 else -1
+    if T < 11:
+        return 100 - (16 * (T - 8) + row)
+    p = 16 * (T - 11) + row
+    return 100 + p if p >= 1 else -1
+
+
 def _emulate(frames, dft, mel, mask, n_mel):
     """Replays frontend_kernel's arithmetic for a (F, 400) float frame matrix in
-    float64, reading the packed float32 tables with the kernel's lane maps."""
+    float64, reading the packed float32 tables with the kernel's lane maps: the odd class's two GEMMs over
+    the 7 tiles U0..3, V0..2, the even class's four (cos | sin) x (ee | eo) over U0..3, the level-C and
+    level-B butterflies, and the mel projection of the 14 power tiles."""
     lib = _lib.lib()
     F = frames.shape[0]
-    acc = np.zeros((4, 112, F))                       # [gemm][folded bin][frame]
     lane = np.arange(64)
+
+    def amat(vec):                                    # lane l: row l & 15, k-lane l >> 4
+        a = np.zeros((16, 4))
+        a[lane & 15, lane >> 4] = vec
+        return a
+
+    def bops(c, step):
+        n = np.array([lib.wfe_dft_n_of(c, step, kk) for kk in range(4)])
+        xf, xb = frames[:, n], frames[:, 400 - n]     # (F, 4); dummies n > 200 read real samples, weights are 0
+        return xf + xb, xf - xb
+
+    co, so = np.zeros((7, 16, F)), np.zeros((7, 16, F))
+    ce, se = np.zeros((2, 4, 16, F)), np.zeros((2, 4, 16, F))        # [ee | eo][tile]
     for s in range(25):
-        for g in range(4):
-            c = g >> 1
-            n = np.array([lib.wfe_dft_n_of(c, s, kk) for kk in range(4)])
-            xf, xb = frames[:, n], frames[:, 400 - n]            # (F, 4)
-            bop = (xf - xb) if (g & 1) else (xf + xb)
-            for bt in range(7):
-                a = dft[s, g, bt >> 2, :, bt & 3].astype(np.float64)   # (64,) lane l: bin l&15, k l>>4
-                amat = np.zeros((16, 4))
-                amat[lane & 15, lane >> 4] = a
-                acc[g, 16 * bt:16 * bt + 16, :] += amat @ bop.T
-    ce, se, co, so = acc
-    P = np.stack([(ce + co) ** 2 + (se + so) ** 2, (ce - co) ** 2 + (se - so) ** 2])   # [family][k][frame]
+        e1, o1 = bops(1, s)
+        for ti in range(7):
+            co[ti] += amat(dft[s, ti >> 2, :, ti & 3].astype(np.float64)) @ e1.T
+            so[ti] += amat(dft[s, 2 + (ti >> 2), :, ti & 3].astype(np.float64)) @ o1.T
+        assert not dft[s, 1, :, 3].any() and not dft[s, 3, :, 3].any()         # the padding tile of quads 1 and 3
+        for t, qc, qs in [(s, 4, 5)] + ([(25, 6, 7)] if s == 24 else []):
+            e0, o0 = bops(0, t)
+            cls = 0 if t < 13 else 1
+            for ti in range(4):
+                ce[cls, ti] += amat(dft[s, qc, :, ti].astype(np.float64)) @ e0.T
+                se[cls, ti] += amat(dft[s, qs, :, ti].astype(np.float64)) @ o0.T
+        if s != 24:
+            assert not dft[s, 6:].any()
+    ce_p, ce_m = ce[0] + ce[1], ce[0] - ce[1]                        # Ce[p], Ce[100 - p]
+    se_p, se_m = se[0] + se[1], se[1] - se[0]                        # Se[p], Se[100 - p]
+    P = np.zeros((14, 16, F))
+    for ti in range(4):
+        P[ti] = (ce_p[ti] + co[ti]) ** 2 + (se_p[ti] + so[ti]) ** 2
+        P[4 + ti] = (ce_p[ti] - co[ti]) ** 2 + (se_p[ti] - so[ti]) ** 2
+    for vt in range(3):
+        P[8 + vt] = (ce_m[vt] + co[4 + vt]) ** 2 + (se_m[vt] + so[4 + vt]) ** 2
+        P[11 + vt] = (ce_m[vt] - co[4 + vt]) ** 2 + (se_m[vt] - so[4 + vt]) ** 2
+    spec = np.full((201, F), np.nan)
+    for T in range(14):
+        for row in range(16):
+            b = _power_bin_of(T, row)
+            if b >= 0:
+                assert np.isnan(spec[b]).all()                           # every bin comes from exactly one position
+                spec[b] = P[T, row]
+    assert not np.isnan(spec).any()
     out = np.zeros((128, F))
-    for f in range(2):
-        for bt in range(7):
-            for mt in range(8):
-                blk = mel[f, bt, mt].astype(np.float64)           # (64 lanes, 4 regs)
-                if not (mask[f * 7 + bt] >> mt) & 1:
-                    assert not blk.any()
-                    continue
-                for r in range(4):
-                    amat = np.zeros((16, 4))
-                    amat[lane & 15, lane >> 4] = blk[:, r]        # mel row l&15, k-lane l>>4
-                    kbins = 16 * bt + 4 * np.arange(4) + r        # folded bins of the 4 k-lanes
-                    out[16 * mt:16 * mt + 16, :] += amat @ P[f][kbins, :]
-    return P, out[:n_mel]
+    for T in range(14):
+        for mt in range(8):
+            blk = mel[T, mt].astype(np.float64)                       # (64 lanes, 4 regs)
+            if not (mask[T] >> mt) & 1:
+                assert not blk.any()
+                continue
+            for r in range(4):
+                out[16 * mt:16 * mt + 16, :] += amat(blk[:, r]) @ P[T][4 * np.arange(4) + r, :]
+    return spec, out[:n_mel]
 
 
 @pytest.mark.parametrize("n_mel", [80, 128])
@@ -105,15 +154,22 @@ def test_packed_tables_reproduce_oracle(n_mel):
     padded, _ = ol.pad_or_trim(wav)
     sel = np.r_[0:3, 400:420, 2997:3000]                # reflect edges + voiced middle + zero tail
     frames = ol.frame_matrix(padded)[sel].astype(np.float64)
-    P, melp = _emulate(frames, dft, mel, mask, n_mel)
+    got_p, melp = _emulate(frames, dft, mel, mask, n_mel)
     want_p = ol.power_spectrum_f64(padded)[:, sel]
-    got_p = np.zeros_like(want_p)
-    got_p[:101] = P[0][:101]
-    got_p[101:] = P[1][:100][::-1]                      # family 1 holds bin 200 - k
     scale = want_p.max()
     assert np.abs(got_p - want_p).max() <= 2e-6 * scale
     want_m = ol.mel_filter_bank(n_mel).T @ want_p
     assert np.abs(melp - want_m).max() <= 2e-6 * want_m.max()
+
+
+def test_compile_time_mel_masks_match_the_builder():
+    """wfe_layout.h kMelMask80 / kMelMask128 (the kernel's straight-line mel phase) against the masks the
+    table builder computes; wfe_create checks the same and falls back to run-time masks otherwise."""
+    layout = open(os.path.join(ROOT, "whisper-finetune_amd", "csrc", "wfe_layout.h")).read()
+    for n_mel in (80, 128):
+        m = re.search(r"kMelMask%d\[14\] = \{([^}]*)\}" % n_mel, layout)
+        want = [int(x, 16) for x in m.group(1).replace(" ", "").split(",")]
+        assert _tables(n_mel)[2].tolist() == want
 
 
 def test_resample_table_matches_oracle_filter():

@@ -112,3 +112,52 @@ for k in np.unique(key)[:400]:
 level_time /= level_time.sum()
 print("SIMD residency between its first and last stamp: 0 waves %.3f, 1 wave %.3f, 2 waves %.3f" % tuple(level_time[:3]))
 print("median (successor start - predecessor end) per SIMD slot: %.0f cycles" % np.median(gaps))
+
+# wave slots: HW_ID[3:0] of the waves that shared a SIMD, in start order (round 3: can the slot's parity tell the two
+# resident workgroups of a CU apart?)
+wid = hw & 15
+print("wave_id histogram:", np.bincount(wid, minlength=16).tolist())
+tg = (hw >> 16) & 15
+print("tg_id histogram:", np.bincount(tg, minlength=16).tolist())
+# do the 4 waves of a workgroup agree on the slot, and do co-resident workgroups differ?
+wg_rows = s[:len(s) // 4 * 4].reshape(-1, 4, s.shape[1])
+wid4 = (wg_rows[:, :, 6] & 15)
+print("workgroups whose 4 waves share one wave_id: %.3f; share its parity: %.3f" % (
+    (wid4 == wid4[:, :1]).all(axis=1).mean(), ((wid4 & 1) == (wid4[:, :1] & 1)).all(axis=1).mean()))
+same_par, n_pairs = 0, 0
+for k in np.unique(key)[:400]:
+    w = s[key == k]
+    w = w[np.argsort(w[:, 0])]
+    ids = w[:, 6] & 15
+    for i in range(len(w)):
+        for j in range(i + 1, len(w)):
+            if w[j, 0] < w[i, 5]:                       # j started before i ended: co-resident
+                n_pairs += 1
+                same_par += int((ids[i] & 1) == (ids[j] & 1))
+            else:
+                break
+print("co-resident wave pairs on a SIMD: %d, with EQUAL wave_id parity: %d" % (n_pairs, same_par))
+k0 = np.unique(key)[0]
+w = s[key == k0]
+w = w[np.argsort(w[:, 0])]
+print("first SIMD, (start, end, wave_id, tg_id):", [(int(a - w[0, 0]), int(b - w[0, 0]), int(c & 15), int((c >> 16) & 15)) for a, b, c in w[:12, [0, 5, 6]]])
+
+# time each SIMD spends with 2 / 1 / 0 waves inside the k-loop, and the k-loop MFMA rate that implies
+# (round 3: 558 MFMAs of 32 cycles per wave and k-loop; the mel MFMAs run outside it)
+X = Y = Z = 0.0
+work = 0.0
+for k in np.unique(key)[:400]:
+    w = s[key == k]
+    ev = sorted([(t, 1) for t in w[:, 2]] + [(t, -1) for t in w[:, 3]])
+    t_first, t_last = w[:, 0].min(), w[:, 5].max()
+    lvl, last = 0, t_first
+    for t, dlt in ev:
+        if lvl >= 2: X += t - last
+        elif lvl == 1: Y += t - last
+        else: Z += t - last
+        lvl, last = lvl + dlt, t
+    Z += t_last - last
+    work += len(w) * float(os.environ.get("WFE_KLOOP_MFMAS", "558")) * 32
+tot_t = X + Y + Z
+print("per SIMD: both in k-loop %.3f, one %.3f, none %.3f of the time; k-loop MFMA cycles / time = %.3f" % (X / tot_t, Y / tot_t, Z / tot_t, work / tot_t))
+print("  if the pipe is full while both are in the k-loop, a k-loop running beside a non-k-loop partner gets %.3f of the pipe" % ((work - X) / max(Y, 1)))

@@ -1146,6 +1146,21 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   // augmented kernel; the k-loop at priority 2 or 3 instead, or both at 0, measured the same or worse;
   // without augmentation the staging is short and the switch costs 1.4 %)
   if (AUG) __builtin_amdgcn_s_setprio(3);
+#ifdef WFE_ASYM
+  // experiment: break the lockstep of the two resident workgroups of a CU.  HW_ID[3:0] is the wave's slot on its
+  // SIMD: 0 or 1 here, different for the two resident workgroups, the same for the 4 waves of one (stamps).
+  const bool slot0 = (__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1u) == 0u;
+#if WFE_ASYM == 1
+  if (slot0) __builtin_amdgcn_s_setprio(1);
+#elif WFE_ASYM == 2 || WFE_ASYM == 4
+  __builtin_amdgcn_s_setprio(3);
+#elif WFE_ASYM == 3
+  if (!slot0 && blockIdx.y * gridDim.x + blockIdx.x < 512) {
+    __builtin_amdgcn_s_sleep(127);
+    __builtin_amdgcn_s_sleep(127);
+  }
+#endif
+#endif
   const Source src = make_source(a, b);
   const float* __restrict__ w = src.w;
   int raw_len = a.lengths[b];
@@ -1185,7 +1200,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
         // clamp, so kernel 2 (which knows the utterance maximum) writes its final value
         // once.  -inf marks the tile as silent; real minima are >= -10.
         if (tid < kTileStats)
-          a.tile_stats[((long long)b * nblk + tx) * kTileStats + tid] = tid < 8 ? -INFINITY : -10.0f;
+          a.tile_stats[((long long)b * nblk + tx) * kTileStats + tid] = tid < 8 ? -INFINITY : -1.5f;      // (g(-10): its maximum)
       }
       return;
     }
@@ -1338,18 +1353,29 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   WFE_STAMP(2);
 
   if (AUG) __builtin_amdgcn_s_setprio(0);
-  // ---- folded DFT as 4 GEMMs on v_mfma_f32_16x16x4_f32
+#if defined(WFE_ASYM) && (WFE_ASYM == 2 || WFE_ASYM == 4)
+  if (slot0) __builtin_amdgcn_s_setprio(WFE_ASYM == 2 ? 2 : 1);
+  else __builtin_amdgcn_s_setprio(0);
+#endif
+  // ---- folded DFT as 6 GEMMs on v_mfma_f32_16x16x4_f32 (wfe_layout.h: levels B and C)
   const int jl = lane & 15;
   const int kk = lane >> 4;
-  const int d_lo = 2 * (kk >> 1) + 16 * (kk & 1);
-  const int d_hi = 2 * kk;
+  const int d_lo = 2 * (kk >> 1) + 16 * (kk & 1);      // odd class, steps 0..23
+  const int d_hi = 2 * kk;                             // odd class, step 24
+  const int d_ev = 4 * (kk >> 1) + 16 * (kk & 1);      // even class
   const int rowbase = 161 * (wave * 16 + jl);          // pad_q(160 * frame-in-block)
 
-  f32x4 acc[4][7];
+  // accumulators: odd class Co / So over the 7 tiles U0..3, V0..2; even class [cos | sin][ee | eo] over U0..3
+  f32x4 acc_o[2][kOddTiles], acc_e[2][2][kEvenTiles];
 #pragma unroll
-  for (int g = 0; g < 4; ++g)
+  for (int g = 0; g < 2; ++g) {
 #pragma unroll
-    for (int bt = 0; bt < 7; ++bt) acc[g][bt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ti = 0; ti < kOddTiles; ++ti) acc_o[g][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cl = 0; cl < 2; ++cl)
+#pragma unroll
+      for (int ti = 0; ti < kEvenTiles; ++ti) acc_e[g][cl][ti] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   // The k-loop, fully unrolled (25 steps) so that every step-dependent index is a
   // compile-time constant and the LDS addresses are lane base + immediate.  The
@@ -1357,51 +1383,90 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   // double-buffered LDS slot, so the CU's L1/TA path carries each of them once per
   // workgroup instead of once per wave.  Everything a step consumes was requested
   // a whole step earlier, and the requests are dealt out between the MFMAs of the
-  // step in four small batches so that the matrix pipe never waits on their issue:
+  // step so that the matrix pipe never waits on their issue:
   //   step s:  MFMA 1,2    | global->reg A(s+4) (2 x 16 B/thread), three register sets in rotation
   //            MFMA 3,4    | reg->LDS A(s+2) into slot s&1 (fetched during step s-2; the slot was
   //                        |   read out in step s-1)
-  //            MFMA 5..12  | LDS->reg the 8 fragment pieces of A(s+1)
-  //            MFMA 13..16 | LDS->reg the 4 samples of step s+1
-  //            MFMA 17..28 | barrier
+  //            MFMA 5..10  | LDS->reg the 6 fragment pieces of A(s+1)
+  //            MFMA 11..14 | LDS->reg the 4 samples of step s+1
+  //            MFMA 15..22 | barrier        (step 23 also requests the two pieces and two samples of even-step 25)
   //   (one request behind each MFMA, pinned there)
+  // k-step s multiplies the odd class's step s (14 MFMAs) and the even class's even-step s (8 MFMAs, class ee
+  // for s < 13, eo after); even-step 25 rides in the last k-step.
   // What keeps hipcc from serialising this (checked in the .s): the two fragment
   // register sets ping-pong (a single set plus a copy gets the copy, and its wait,
   // hoisted to a few MFMAs after the reads); scheduling barriers pin each batch
-  // (otherwise requests sink to their first use); the 8th, padding, twiddle is never
+  // (otherwise requests sink to their first use); the padding twiddles are never
   // read (a dead destination register is reused at once and forces a wait).
-  float xf[2], xb[2];
-  const int lane_lo = rowbase + d_lo, lane_hi = rowbase + d_hi;
-  auto sample_request = [&](int s, int c, int backward) {
-    // n = dft_n_of(c, s, kk) = nb + delta(lane) + c0, c0 = 2 (even class) or 1 (odd)
-    const bool tail = s == kSteps - 1;
-    const int nb = tail ? 192 : (32 * (s >> 2) + 4 * (s & 3));
-    const int dl = tail ? d_hi : d_lo;
-    const int base = tail ? lane_hi : lane_lo;
-    const int c0 = c ? 1 : 2;
-    const int nn = nb + dl + c0;                       // 1..200
-    const int mm = kNfft - nn;                         // 200..399
+  float xf[2], xb[2], xf2 = 0.f, xb2 = 0.f;            // [0] even class, [1] odd class; xf2 / xb2: even-step 25
+  // Lane bases of the sample reads, forward (x[n]) and backward (x[400 - n]) for the three k-lane patterns: six LDS
+  // pointers, made opaque so that each stays in ONE register for the whole k-loop and every read is base +
+  // immediate (hipcc otherwise rebuilds the backward ones from their parts with two VALU instructions per read:
+  // 96 per tile, next to the MFMA stream).
+  using lds_cptr = const __attribute__((address_space(3))) float*;
+  lds_cptr fw_lo = (lds_cptr)(lds + rowbase + d_lo), fw_hi = (lds_cptr)(lds + rowbase + d_hi), fw_ev = (lds_cptr)(lds + rowbase + d_ev);
+  lds_cptr bw_lo = (lds_cptr)(lds + rowbase - d_lo), bw_hi = (lds_cptr)(lds + rowbase - d_hi), bw_ev = (lds_cptr)(lds + rowbase - d_ev);
+  asm volatile("" : "+v"(fw_lo), "+v"(fw_hi), "+v"(fw_ev), "+v"(bw_lo), "+v"(bw_hi), "+v"(bw_ev));
+  // sample n = dft_n_of(c, step, kk) of this lane's frame, or its mirror 400 - n
+  auto sample_at = [&](int step, int c, int backward) {
+    int nb, dl, c0;
+    lds_cptr fw, bw;
+    if (c) {
+      const bool tail = step == kSteps - 1;
+      nb = tail ? 192 : (32 * (step >> 2) + 4 * (step & 3));
+      dl = tail ? d_hi : d_lo;
+      fw = tail ? fw_hi : fw_lo;
+      bw = tail ? bw_hi : bw_lo;
+      c0 = 1;
+    } else {
+      const int u = step < 13 ? step : step - 13;
+      nb = u < 12 ? 32 * (u >> 1) + 8 * (u & 1) : 192;
+      dl = d_ev;
+      fw = fw_ev;
+      bw = bw_ev;
+      c0 = step < 13 ? 4 : 2;
+    }
+    const int nn = nb + dl + c0;                       // 1..216 (beyond 200: the dummy k-lanes, zero twiddles)
+    const int mm = kNfft - nn;
     // pad_q(160 j + x) = 161 j + x + x / 160; the x / 160 term is a compile-time
     // constant except in the few steps whose 4 k-lanes straddle 160 or 320
-    if (backward) xb[c] = lds[2 * rowbase - base + kNfft - nb - c0 + 1 + (mm >= 2 * kHop ? 1 : 0)];
-    else xf[c] = lds[base + nb + c0 + (nn >= kHop ? 1 : 0)];
+    if (backward) return bw[kNfft - nb - c0 + 1 + (mm >= 2 * kHop ? 1 : 0)];
+    return fw[nb + c0 + (nn >= kHop ? 1 : 0)];
+  };
+  auto sample_request = [&](int step, int c, int backward) {
+    if (backward) xb[c] = sample_at(step, c, 1);
+    else xf[c] = sample_at(step, c, 0);
   };
 #ifdef WFE_STAMPS
   unsigned long long barrier_cycles = 0;
 #endif
-  Frag7 Ra[4], Rb[4];
+  struct StepFrag {
+    Frag7 oc, os;                                      // odd class: cos, sin rows of the 7 tiles
+    f32x4 ec, es;                                      // even class: cos, sin rows of U0..3
+  };
+  auto load_frag = [&](StepFrag& f, const f32x4* slot, int piece) {      // piece 0..5 of the step's 6
+    if (piece == 0) f.oc.lo = slot[0];
+    else if (piece == 1) f.oc.hi = *reinterpret_cast<const f32x3*>(slot + 64);
+    else if (piece == 2) f.os.lo = slot[128];
+    else if (piece == 3) f.os.hi = *reinterpret_cast<const f32x3*>(slot + 192);
+    else if (piece == 4) f.ec = slot[256];
+    else f.es = slot[320];
+  };
+  StepFrag Ra, Rb;
+  f32x4 ec2 = f32x4{0.f, 0.f, 0.f, 0.f}, es2 = ec2;    // even-step 25 (quads 6, 7 of the last k-step)
 #pragma unroll
-  for (int g = 0; g < 4; ++g) Ra[g] = load_frag7(slots + lane + g * 128);
+  for (int pc = 0; pc < 6; ++pc) load_frag(Ra, slots + lane, pc);
 #pragma unroll
   for (int i = 0; i < 4; ++i) sample_request(0, i >> 1, i & 1);
   __syncthreads();      // slot 0 is overwritten in the middle of step 0: every wave must have read it out
 #pragma unroll
   for (int s = 0; s < kSteps; ++s) {
-    Frag7(&Rc)[4] = (s & 1) ? Rb : Ra;
-    Frag7(&Rn)[4] = (s & 1) ? Ra : Rb;
-    const bool next = s + 1 < kSteps, stage = s + kAhead < kSteps;
+    StepFrag& Rc = (s & 1) ? Rb : Ra;
+    StepFrag& Rn = (s & 1) ? Ra : Rb;
+    const bool next = s + 1 < kSteps, stage = s + kAhead < kSteps, last = s == kSteps - 1;
     const f32x4* nslot = slots + ((s + 1) % kSlots) * 512 + lane;
-    float e[2], o[2];
+    const int cl = s < 13 ? 0 : 1;                     // class of even-step s
+    float e[2], o[2], e2 = 0.f, o2 = 0.f;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
 #if WFE_ABLATE & 256
@@ -1412,38 +1477,54 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
       o[c] = xf[c] - xb[c];
 #endif
     }
-    auto mfma = [&](int g, int bt) {
-      acc[g][bt] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rc[g].at(bt), (g & 1) ? o[g >> 1] : e[g >> 1], acc[g][bt],
-                                                        0, 0, 0);
+    if (last) e2 = xf2 + xb2, o2 = xf2 - xb2;
+    constexpr int kMain = 2 * kOddTiles + 2 * kEvenTiles;          // 22
+    auto mfma = [&](int m) {
+      if (m < kOddTiles)
+        acc_o[0][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rc.oc.at(m), e[1], acc_o[0][m], 0, 0, 0);
+      else if (m < 2 * kOddTiles)
+        acc_o[1][m - kOddTiles] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rc.os.at(m - kOddTiles), o[1], acc_o[1][m - kOddTiles], 0, 0, 0);
+      else if (m < 2 * kOddTiles + kEvenTiles)
+        acc_e[0][cl][m - 14] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rc.ec[m - 14], e[0], acc_e[0][cl][m - 14], 0, 0, 0);
+      else if (m < kMain)
+        acc_e[1][cl][m - 18] = __builtin_amdgcn_mfma_f32_16x16x4f32(Rc.es[m - 18], o[0], acc_e[1][cl][m - 18], 0, 0, 0);
+      else if (m < kMain + kEvenTiles)                             // even-step 25 (class eo), last k-step only
+        acc_e[0][1][m - 22] = __builtin_amdgcn_mfma_f32_16x16x4f32(ec2[m - 22], e2, acc_e[0][1][m - 22], 0, 0, 0);
+      else
+        acc_e[1][1][m - 26] = __builtin_amdgcn_mfma_f32_16x16x4f32(es2[m - 26], o2, acc_e[1][1][m - 26], 0, 0, 0);
     };
     f32x4(&Gw)[2] = G[(s + kAhead) % 3];        // holds A(s + kAhead), requested during step s-2
     f32x4(&Gr)[2] = G[(s + kAhead + 2) % 3];    // receives A(s + kAhead + 2)
-    // the 16 requests of a step, one behind each of the first 16 MFMAs (a clump of
+    // the requests of a step, one behind each of its first MFMAs (a clump of
     // them between two MFMAs idles the matrix pipe for the clump's issue time)
     auto request = [&](int i) {
       if (i < 2) {                                          // global -> registers, A(s + kAhead + 2)
         if (s + kAhead + 2 < kSteps) Gr[i] = tw_load((s + kAhead + 2) * 512 + 256 * i);
       } else if (i < 4) {                                   // registers -> LDS, A(s + kAhead)
         if (stage) slots[((s + kAhead) % kSlots) * 512 + 256 * (i - 2) + tid] = Gw[i - 2];
-      } else if (i < 12) {                                  // LDS -> registers, fragments of A(s+1)
-        const int g = (i - 4) >> 1;
-        if (next) {
-          if ((i - 4) & 1) Rn[g].hi = *reinterpret_cast<const f32x3*>(nslot + g * 128 + 64);
-          else Rn[g].lo = nslot[g * 128];
-        }
-      } else if (next) {                  // LDS -> registers, samples of step s+1
-        sample_request(s + 1, (i - 12) >> 1, (i - 12) & 1);
+      } else if (i < 10) {                                  // LDS -> registers, fragments of A(s+1)
+        if (next) load_frag(Rn, nslot, i - 4);
+      } else if (i < 14) {                                  // LDS -> registers, samples of step s+1
+        if (next) sample_request(s + 1, (i - 10) >> 1, (i - 10) & 1);
+      } else if (s + 2 == kSteps) {                         // for the last k-step: even-step 25 as well
+        if (i == 14) ec2 = nslot[384];
+        else if (i == 15) es2 = nslot[448];
+        else if (i == 16) xf2 = sample_at(kEvenSteps - 1, 0, 0);
+        else if (i == 17) xb2 = sample_at(kEvenSteps - 1, 0, 1);
       }
     };
+    const int n_mfma = last ? kMain + 2 * kEvenTiles : kMain;
 #pragma unroll
-    for (int m = 0; m < 28; ++m) {
-      mfma(m / 7, m % 7);
-      __builtin_amdgcn_sched_barrier(0);
-      if (m < 16) {
-#if !(WFE_ABLATE & 128)
-        request(m);
-#endif
+    for (int m = 0; m < kMain + 2 * kEvenTiles; ++m) {
+      if (m < n_mfma) {
+        mfma(m);
         __builtin_amdgcn_sched_barrier(0);
+        if (m < 18) {
+#if !(WFE_ABLATE & 128)
+          request(m);
+#endif
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
 #ifdef WFE_STAMPS
@@ -1466,108 +1547,107 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   if (a.stamps && lane == 0)
     a.stamps[((long long)(blockIdx.y * ((a.n_frames + 63) / 64) + tx) * 4 + wave) * kStampRow + 7] = barrier_cycles;
 #endif
+#ifdef WFE_EPI_PRIO           // experiment: the epilogue's vector instructions outrank the partner's MFMA stream
+  __builtin_amdgcn_s_setprio(WFE_EPI_PRIO);
+#endif
+#if defined(WFE_ASYM) && (WFE_ASYM == 2 || WFE_ASYM == 4)
+  __builtin_amdgcn_s_setprio(3);
+#endif
   // Mel weight fragments of every live (bin tile, mel tile) block: all requested
   // here, ahead of the butterflies, so that the mel phase pays one L2 round trip
   // instead of one per block (the scheduling barrier pins the batch).
   // (buffer loads for the same reason as the twiddles: block offset in an SGPR, no VALU address math)
   const __amdgpu_buffer_rsrc_t mel_rsrc =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.mel_tab), 0, (int)(kMelTableFloats * 4), 0x00020000);
-  f32x4 wv[2][7][NMT];
+  f32x4 wv[kPowerTiles][NMT];
   if (!POWER && BANK != 0) {
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+    for (int pt = 0; pt < kPowerTiles; ++pt)
 #pragma unroll
-      for (int bt = 0; bt < 7; ++bt)
-#pragma unroll
-        for (int mt = 0; mt < NMT; ++mt)
-          if (((BANK == 1 ? kMelMask80[f * 7 + bt] : kMelMask128[f * 7 + bt]) >> mt) & 1u)
-            wv[f][bt][mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                mel_rsrc, lane * 16, ((f * 7 + bt) * kMelTiles + mt) * 64 * 16, 0));
+      for (int mt = 0; mt < NMT; ++mt)
+        if (((BANK == 1 ? kMelMask80[pt] : kMelMask128[pt]) >> mt) & 1u)
+          wv[pt][mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+              mel_rsrc, lane * 16, (pt * kMelTiles + mt) * 64 * 16, 0));
     __builtin_amdgcn_sched_barrier(0);
   }
-  // ---- butterflies + power: family 0 = bin k, family 1 = bin 200 - k
-  // (on register PAIRS where hipcc agrees: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 do two values per
-  // instruction, and every VALU instruction next to the partner wave's MFMA stream costs the matrix
-  // pipe 5..9 cycles -- tools/micro/mfma_issue.hip.  The same arithmetic spelled as inline-asm packed
-  // instructions packs every pair but reads accumulators behind the hazard recognizer's back: wrong
-  // results even behind explicit wait states, so the compiler-visible form stays.)
-  f32x4 P[2][7];
+  // ---- butterflies + power (wfe_layout.h).  Level C on the even class: position p of U tile ti gives
+  // Ce[p], Se[p] (sums) and Ce[100-p], Se[100-p] (differences); level B pairs them with the odd class's rows
+  // of U (bins p, 200 - p) and of V (bins 100 - p, 100 + p).  Every butterfly combines accumulators of one
+  // lane and register.  Power tiles: U lo 0..3, U hi 4..7, V a 8..10, V b 11..13.
+  // (Scalar f32 instructions: beside the partner wave's MFMA stream a packed v_pk_add / v_pk_fma costs the
+  // matrix pipe more than the two scalar ones it replaces -- tools/micro/mfma_fillers.hip.)
+  f32x4 P[kPowerTiles];
 #pragma unroll
-  for (int bt = 0; bt < 7; ++bt) {
-    f32x2 p0[2], p1[2];
-#pragma unroll
-    for (int hh = 0; hh < 2; ++hh) {
-      const f32x2 ce = hh ? __builtin_shufflevector(acc[0][bt], acc[0][bt], 2, 3) : __builtin_shufflevector(acc[0][bt], acc[0][bt], 0, 1);
-      const f32x2 se = hh ? __builtin_shufflevector(acc[1][bt], acc[1][bt], 2, 3) : __builtin_shufflevector(acc[1][bt], acc[1][bt], 0, 1);
-      const f32x2 co = hh ? __builtin_shufflevector(acc[2][bt], acc[2][bt], 2, 3) : __builtin_shufflevector(acc[2][bt], acc[2][bt], 0, 1);
-      const f32x2 so = hh ? __builtin_shufflevector(acc[3][bt], acc[3][bt], 2, 3) : __builtin_shufflevector(acc[3][bt], acc[3][bt], 0, 1);
+  for (int ti = 0; ti < kUTiles; ++ti) {
 #if WFE_ABLATE & 2
-      p0[hh] = ce + so;                         // (all four GEMMs stay live)
-      p1[hh] = se + co;
+    P[ti] = acc_e[0][0][ti] + acc_e[1][1][ti] + acc_o[0][ti];       // (all GEMMs stay live)
+    P[4 + ti] = acc_e[0][1][ti] + acc_e[1][0][ti] + acc_o[1][ti];
+    if (ti < kVTiles) P[8 + ti] = acc_o[0][4 + ti], P[11 + ti] = acc_o[1][4 + ti];
 #else
-      const f32x2 rp = ce + co, ip = se + so, rm = ce - co, im = se - so;
-      p0[hh] = __builtin_elementwise_fma(rp, rp, ip * ip);
-      p1[hh] = __builtin_elementwise_fma(rm, rm, im * im);
-#endif
+    const f32x4 ce = acc_e[0][0][ti] + acc_e[0][1][ti], se = acc_e[1][0][ti] + acc_e[1][1][ti];
+    {
+      const f32x4 co = acc_o[0][ti], so = acc_o[1][ti];
+      const f32x4 rp = ce + co, ip = se + so, rm = ce - co, im = se - so;
+      P[ti] = __builtin_elementwise_fma(rp, rp, ip * ip);
+      P[4 + ti] = __builtin_elementwise_fma(rm, rm, im * im);
     }
-    P[0][bt] = __builtin_shufflevector(p0[0], p0[1], 0, 1, 2, 3);
-    P[1][bt] = __builtin_shufflevector(p1[0], p1[1], 0, 1, 2, 3);
+    if (ti < kVTiles) {
+      const f32x4 cm = acc_e[0][0][ti] - acc_e[0][1][ti], sm = acc_e[1][1][ti] - acc_e[1][0][ti];
+      const f32x4 co = acc_o[0][4 + ti], so = acc_o[1][4 + ti];
+      const f32x4 rp = cm + co, ip = sm + so, rm = cm - co, im = sm - so;
+      P[8 + ti] = __builtin_elementwise_fma(rp, rp, ip * ip);
+      P[11 + ti] = __builtin_elementwise_fma(rm, rm, im * im);
+    }
+#endif
   }
   const int frame = t0 + wave * 16 + jl;
 
   if (POWER) {
     float* __restrict__ po = a.out + (long long)b * kNfreq * T;
 #pragma unroll
-    for (int bt = 0; bt < 7; ++bt)
+    for (int pt = 0; pt < kPowerTiles; ++pt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int k = 16 * bt + 4 * kk + r;
-        if (frame < T && k < kFoldBins) {
-          po[(long long)k * T + frame] = P[0][bt][r];
-          if (k < kFoldBins - 1) po[(long long)(200 - k) * T + frame] = P[1][bt][r];
-        }
+        const int bin = power_bin_of(pt, 4 * kk + r);
+        if (frame < T && bin >= 0) po[(long long)bin * T + frame] = P[pt][r];
       }
     return;
   }
 
-  // ---- mel projection on the same MFMA; all-zero (bin tile, mel tile) blocks skipped
+  // ---- mel projection on the same MFMA; all-zero (power tile, mel tile) blocks skipped
   f32x4 m[NMT];
 #pragma unroll
   for (int mt = 0; mt < NMT; ++mt) m[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (BANK != 0) {
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+    for (int pt = 0; pt < kPowerTiles; ++pt)
 #pragma unroll
-      for (int bt = 0; bt < 7; ++bt)
+      for (int mt = 0; mt < NMT; ++mt)
+        if (((BANK == 1 ? kMelMask80[pt] : kMelMask128[pt]) >> mt) & 1u) {
 #pragma unroll
-        for (int mt = 0; mt < NMT; ++mt)
-          if (((BANK == 1 ? kMelMask80[f * 7 + bt] : kMelMask128[f * 7 + bt]) >> mt) & 1u) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
+          for (int r = 0; r < 4; ++r)
 #if WFE_ABLATE & 4
-              m[mt][r] += wv[f][bt][mt][r] + P[f][bt][r];
+            m[mt][r] += wv[pt][mt][r] + P[pt][r];
 #else
-              m[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[f][bt][mt][r], P[f][bt][r], m[mt], 0, 0, 0);
+            m[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[pt][mt][r], P[pt][r], m[mt], 0, 0, 0);
 #endif
-          }
+        }
   } else {
 #pragma unroll
-    for (int f = 0; f < 2; ++f)
+    for (int pt = 0; pt < kPowerTiles; ++pt) {
+      const unsigned mask = a.mel_mask[pt];
 #pragma unroll
-      for (int bt = 0; bt < 7; ++bt) {
-        const unsigned mask = a.mel_mask[f * 7 + bt];
+      for (int mt = 0; mt < NMT; ++mt) {
+        if ((mask >> mt) & 1u) {
+          // uniform base + 32-bit lane offset: keeps the address in SGPRs (one VGPR
+          // pair per block would spill in this run-time-mask build)
+          const f32x4 w4 = reinterpret_cast<const f32x4*>(a.mel_tab)[(pt * kMelTiles + mt) * 64 + lane];
 #pragma unroll
-        for (int mt = 0; mt < NMT; ++mt) {
-          if ((mask >> mt) & 1u) {
-            // uniform base + 32-bit lane offset: keeps the address in SGPRs (one VGPR
-            // pair per block would spill in this run-time-mask build)
-            const f32x4 w4 = reinterpret_cast<const f32x4*>(a.mel_tab)[((f * 7 + bt) * kMelTiles + mt) * 64 + lane];
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              m[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[r], P[f][bt][r], m[mt], 0, 0, 0);
-          }
+          for (int r = 0; r < 4; ++r)
+            m[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[r], P[pt][r], m[mt], 0, 0, 0);
         }
       }
+    }
   }
   WFE_STAMP(4);
 
@@ -1584,8 +1664,17 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   // log values of the max / min powers, exactly -- three-input max / min over the accumulators, then
   // the log of two wave-uniform numbers, instead of two instructions per value.
   const bool frame_ok = frame < T;
-  auto log10_floor = [](float pw) {
-    return (pw > 1e-10f) ? __builtin_amdgcn_logf(pw) * 0.30102999566398120f : -10.0f;
+  // g(log10(max(pw, 1e-10))) in three instructions per value (round 3; five before): v_log_f32, one fma with
+  // log10(2) / 4 folded into the multiplier, and a max against g(-10) = -1.5 -- the floor of clamp(min=1e-10):
+  // powers at or below it (silence, padding: by far the most common value) give exactly -1.5, and the map
+  // stays monotone, which is all the statistics and kernel 2 rely on.  Within 1.5e-7 of the five-instruction
+  // form (one rounding fewer).
+  auto g_of = [](float pw) {
+#if WFE_ABLATE & 8
+    return pw;
+#else
+    return __builtin_fmaxf(__builtin_fmaf(__builtin_amdgcn_logf(pw), 0.25f * 0.30102999566398120f, 1.0f), -1.5f);
+#endif
   };
   float pmax = -INFINITY, pmin = INFINITY;
 #pragma unroll
@@ -1609,20 +1698,16 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   pmax = wave_reduce<true>(frame_ok ? pmax : -INFINITY);
   pmin = wave_reduce<false>(frame_ok ? pmin : INFINITY);
 #endif
+  // statistics in the STORED scale (g): g of the extreme powers = the extremes of the stored values, exactly
   // (a wave without a valid frame leaves -inf / +inf, as before)
-  const float wmax = pmax == -INFINITY ? -INFINITY : log10_floor(pmax);
-  const float wmin = pmin == INFINITY ? INFINITY : log10_floor(pmin);
+  const float wmax = pmax == -INFINITY ? -INFINITY : g_of(pmax);
+  const float wmin = pmin == INFINITY ? INFINITY : g_of(pmin);
 #pragma unroll
   for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int mel = 16 * mt + 4 * kk + r;
-      // (v + 4) / 4 as one fma: v / 4 + 1 rounds once, to the same float32 as (v + 4) * 0.25
-#if WFE_ABLATE & 8
-      tile[mel * kTileStride + wave * 16 + jl] = m[mt][r];
-#else
-      tile[mel * kTileStride + wave * 16 + jl] = __builtin_fmaf(log10_floor(m[mt][r]), 0.25f, 1.0f);
-#endif
+      tile[mel * kTileStride + wave * 16 + jl] = g_of(m[mt][r]);
     }
   if (lane == 0) {
     float* st = a.tile_stats + ((long long)b * nblk + tx) * kTileStats;
@@ -1704,11 +1789,11 @@ __global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ out, int
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = gmax;
   __syncthreads();
   gmax = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
-  const float floor_v = gmax - 8.0f;
+  // the statistics are in the stored scale g(v) = (v + 4) / 4: g(max - 8) = g(max) - 2
+  const float floor_g = gmax - 2.0f;
   const float* bm = tile_stats + ((long long)b * nblk + tx) * kTileStats;   // [frame group 4][wave of the pair 2]
   // decided per half tile (32 frames): two frame groups, each with the minima of its (up to two) waves
   const int tid = threadIdx.x;
-  const float floor_g = (floor_v + 4.0f) * 0.25f;
   if (out_kind != 0) {
     // 16-bit output: max(h, round(floor)) on the stored halves == round(max(g(v), floor))
     const bool bf = out_kind == 2;
@@ -1719,7 +1804,7 @@ __global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ out, int
     const float ff = from16(hf, bf);
     for (int h = 0; h < 2; ++h) {
       const float lowest = fminf(fminf(bm[4 * h], bm[4 * h + 1]), fminf(bm[4 * h + 2], bm[4 * h + 3]));
-      if (!(lowest < floor_v)) continue;
+      if (!(lowest < floor_g)) continue;
       const int t0 = tx * kBlockFrames + 32 * h;
       if (t0 >= T) continue;
       const int frames_here = (T - t0 < 32) ? (T - t0) : 32;
@@ -1762,7 +1847,7 @@ __global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ out, int
   const bool vec = (T & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
   for (int h = 0; h < 2; ++h) {
     const float lowest = fminf(fminf(bm[4 * h], bm[4 * h + 1]), fminf(bm[4 * h + 2], bm[4 * h + 3]));
-    if (!(lowest < floor_v)) continue;
+    if (!(lowest < floor_g)) continue;
     const int t0 = tx * kBlockFrames + 32 * h;
     if (t0 >= T) continue;
     const int frames_here = (T - t0 < 32) ? (T - t0) : 32;
@@ -2688,6 +2773,12 @@ static hipError_t launch_k1(const FrontArgs& a, int batch, hipStream_t stream) {
 // bank: 1 = the 80-mel Whisper bank, 2 = the 128-mel bank (compile-time block
 // masks), 0 = any other feature_size (run-time masks).
 hipError_t launch_frontend(const FrontArgs& a, int batch, int mode, bool aug, int bank, hipStream_t stream) {
+#ifdef WFE_FAST_BUILD          // experiment builds (minutes less to compile): the two plain log-mel kernels only
+  if (mode == 0 && !aug && bank == 1) return launch_k1<5, false, false, 1>(a, batch, stream);
+  if (mode == 0 && !aug && bank == 2) return launch_k1<8, false, false, 2>(a, batch, stream);
+  if (mode == 1 && !aug) return launch_k1<5, true, false, 0>(a, batch, stream);
+  return hipErrorInvalidValue;
+#else
   if (mode == 1)
     return aug ? launch_k1<5, true, true, 0>(a, batch, stream) : launch_k1<5, true, false, 0>(a, batch, stream);
   if (bank == 1)
@@ -2697,6 +2788,7 @@ hipError_t launch_frontend(const FrontArgs& a, int batch, int mode, bool aug, in
   if (a.n_mel <= 80)
     return aug ? launch_k1<5, false, true, 0>(a, batch, stream) : launch_k1<5, false, false, 0>(a, batch, stream);
   return aug ? launch_k1<8, false, true, 0>(a, batch, stream) : launch_k1<8, false, false, 0>(a, batch, stream);
+#endif
 }
 
 hipError_t launch_clamp(float* out, int out_kind, const float* tile_stats, int batch, int n_mel, int n_frames,
@@ -2714,12 +2806,18 @@ hipError_t launch_noise_meansq(const float* noise, const long long* off, int n_n
 }
 
 hipError_t launch_resolve(const FrontArgs& a, int batch, double* partials, unsigned* tickets, hipStream_t stream) {
+#ifdef WFE_FAST_BUILD
+  return hipErrorInvalidValue;
+#endif
   hipLaunchKernelGGL(resolve_partial_kernel, dim3(kResolveParts, batch), dim3(256), 0, stream, a, partials, tickets);
   return hipGetLastError();
 }
 
 hipError_t launch_waveform(const FrontArgs& a, int batch, float* out, int* out_lengths, hipStream_t stream) {
   const int gx = (a.n_samples + kBlockFrames * kHop - 1) / (kBlockFrames * kHop);
+#ifdef WFE_FAST_BUILD
+  return hipErrorInvalidValue;
+#endif
   hipLaunchKernelGGL(waveform_kernel, dim3(gx < 1 ? 1 : gx, batch), dim3(256), 0, stream, a, out, out_lengths);
   return hipGetLastError();
 }

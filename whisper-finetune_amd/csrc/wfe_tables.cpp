@@ -60,56 +60,66 @@ extern "C" int64_t wfe_dft_table_floats(void) { return wfe::kDftTableFloats; }
 extern "C" int64_t wfe_mel_table_floats(void) { return wfe::kMelTableFloats; }
 extern "C" int32_t wfe_dft_n_of(int32_t c, int32_t s, int32_t kk) { return wfe::dft_n_of(c, s, kk); }
 
-// [step][gemm][half][lane][j]: A operand of v_mfma_f32_16x16x4_f32 -- lane l
-// holds A[row = l & 15][k = l >> 4]; row = bin inside bin tile (4*half + j),
-// k = the n assigned to k-lane l >> 4 of this step.
+// One entry of the folded-DFT matrices: Hann window times cos / sin of bin row k at sample n.
+// k < 0 (unused row) and n > 200 (dummy k-lane of a class's last even-step) give 0.
+namespace {
+double twiddle(int k, int n, bool sine) {
+  using namespace wfe;
+  if (k < 0 || n > kHalf) return 0.0;
+  const double w = 0.5 - 0.5 * std::cos(2.0 * kPi * (double)n / (double)kNfft);
+  const int r = (k * n) % kNfft;                    // exact angle reduction
+  const double ang = 2.0 * kPi * (double)r / (double)kNfft;
+  double v = w * (sine ? std::sin(ang) : std::cos(ang));
+  if (n == kHalf) v = sine ? 0.0 : 0.5 * v;         // e[200] = 2 x[200]; o[200] = 0
+  return v;
+}
+}  // namespace
+
+// [step][quad][lane][j] (wfe_layout.h): A operand of v_mfma_f32_16x16x4_f32 -- lane l holds
+// A[row = l & 15][k-lane = l >> 4] of tile j of the quad; the row's bin frequency comes from
+// odd_row_of / even_row_of, the k-lane's n from dft_n_of.
 extern "C" int wfe_build_dft_table(float* out) {
   if (!out) return WFE_ERR_ARG;
   using namespace wfe;
   for (int s = 0; s < kSteps; ++s)
-    for (int g = 0; g < kGemms; ++g)
-      for (int half = 0; half < 2; ++half)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int j = 0; j < 4; ++j) {
-            const int bt = 4 * half + j;
-            const int k = 16 * bt + (lane & 15);
-            const int n = dft_n_of(g >> 1, s, lane >> 4);
-            double v = 0.0;
-            if (bt < kBinTiles && k < kFoldBins) {
-              const double w = 0.5 - 0.5 * std::cos(2.0 * kPi * (double)n / (double)kNfft);
-              const int r = (k * n) % kNfft;                    // exact angle reduction
-              const double ang = 2.0 * kPi * (double)r / (double)kNfft;
-              v = w * ((g & 1) ? std::sin(ang) : std::cos(ang));
-              if (n == kHalf) v = (g & 1) ? 0.0 : 0.5 * v;      // e[200] = 2 x[200]; o[200] = 0
-            }
-            out[((((size_t)s * kGemms + g) * 2 + half) * 64 + lane) * 4 + j] = (float)v;
+    for (int q = 0; q < kDftQuads; ++q)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 4; ++j) {
+          const int row = lane & 15, kk = lane >> 4;
+          double v = 0.0;
+          if (q < 4) {                                         // odd class: Co (q 0, 1), So (q 2, 3)
+            const int ti = 4 * (q & 1) + j;
+            if (ti < kOddTiles) v = twiddle(odd_row_of(ti, row), dft_n_of(1, s, kk), q >= 2);
+          } else if (q < 6) {                                  // even class, even-step s
+            v = twiddle(even_row_of(j, row), dft_n_of(0, s, kk), q == 5);
+          } else if (s == kSteps - 1) {                        // even-step 25 rides in the last k-step
+            v = twiddle(even_row_of(j, row), dft_n_of(0, kEvenSteps - 1, kk), q == 7);
           }
+          out[(((size_t)s * kDftQuads + q) * 64 + lane) * 4 + j] = (float)v;
+        }
   return WFE_OK;
 }
 
-// [family][bin tile][mel tile][lane][r]: A operand of the mel MFMA -- lane l
-// holds A[row = mel 16*mt + (l & 15)][k = l >> 4] for the power register r, whose
-// lanes carry folded bin k = 16*bt + 4*(l >> 4) + r (the C/D layout of the DFT
-// MFMA).  family 0 is spectrum bin k, family 1 is bin 200 - k.
+// [power tile][mel tile][lane][r]: A operand of the mel MFMA -- lane l holds
+// A[row = mel 16*mt + (l & 15)][k = l >> 4] for the power register r, whose lanes carry the spectrum bin
+// power_bin_of(T, 4 * (l >> 4) + r) (the C/D layout of the DFT MFMA).
 extern "C" int wfe_build_mel_table(int32_t n_mel, float* out, uint32_t* mask14) {
   if (!out || !mask14 || n_mel < 1 || n_mel > wfe::kMaxMel) return WFE_ERR_ARG;
   using namespace wfe;
   std::vector<double> bank((size_t)kNfreq * n_mel);
   wfe_build_mel_filters(n_mel, bank.data());
-  for (int i = 0; i < 2 * kBinTiles; ++i) mask14[i] = 0;
-  for (int f = 0; f < 2; ++f)
-    for (int bt = 0; bt < kBinTiles; ++bt)
-      for (int mt = 0; mt < kMelTiles; ++mt)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int r = 0; r < 4; ++r) {
-            const int mel = 16 * mt + (lane & 15);
-            const int k = 16 * bt + 4 * (lane >> 4) + r;
-            float v = 0.f;
-            const bool live = mel < n_mel && k < kFoldBins && !(f == 1 && k == kFoldBins - 1);
-            if (live) v = (float)bank[(size_t)(f ? 200 - k : k) * n_mel + mel];
-            if (v != 0.f) mask14[f * kBinTiles + bt] |= 1u << mt;
-            out[((((size_t)f * kBinTiles + bt) * kMelTiles + mt) * 64 + lane) * 4 + r] = v;
-          }
+  for (int i = 0; i < kPowerTiles; ++i) mask14[i] = 0;
+  for (int T = 0; T < kPowerTiles; ++T)
+    for (int mt = 0; mt < kMelTiles; ++mt)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int r = 0; r < 4; ++r) {
+          const int mel = 16 * mt + (lane & 15);
+          const int bin = power_bin_of(T, 4 * (lane >> 4) + r);
+          float v = 0.f;
+          if (mel < n_mel && bin >= 0) v = (float)bank[(size_t)bin * n_mel + mel];
+          if (v != 0.f) mask14[T] |= 1u << mt;
+          out[(((size_t)T * kMelTiles + mt) * 64 + lane) * 4 + r] = v;
+        }
   return WFE_OK;
 }
 
