@@ -115,7 +115,7 @@ int wfe_logmel(wfe_handle h, const float* wav, const int64_t* offsets, const int
  * serving loops, harnesses that forbid allocation.  Same arguments, same kernels and bit for
  * bit the same output as wfe_logmel (it honours wfe_set_output_format too); the per-tile
  * statistics the first kernel leaves for the clamp kernel live in a static device array of the
- * library (577 536 bytes, held on every GPU the library runs on until the process ends) instead
+ * library (1 732 608 bytes, held on every GPU the library runs on until the process ends) instead
  * of the handle's workspace, and the call itself allocates nothing, creates no event and is
  * never timed by wfe_kernel_timing.
  *   limit   batch * ceil((n_samples / 160) / 64) <= 12032 tiles (256 utterances of 30 s) and
@@ -123,7 +123,7 @@ int wfe_logmel(wfe_handle h, const float* wav, const int64_t* offsets, const int
  *   sharing every call on one GPU -- whatever the handle or stream -- uses that GPU's one array:
  *           calls that overlap on a GPU race; order them on one stream or with events.  The
  *           array keeps the last call's contents; nothing has to start at zero (kernel 1
- *           writes all 12 statistics of every tile before the clamp kernel reads them). */
+ *           writes all 36 statistics of every tile before the clamp kernel reads them). */
 int wfe_logmel_static(wfe_handle h, const float* wav, const int64_t* offsets, const int32_t* lengths,
                       int64_t row_stride, int32_t batch, int32_t n_samples, float* out, void* stream);
 
@@ -141,6 +141,14 @@ int wfe_augment_logmel(wfe_handle h, const float* wav, const int64_t* offsets, c
                        const wfe_aug_op* ops, const int32_t* op_begin, int64_t total_ops,
                        const float* noise, const int64_t* noise_offsets, int32_t n_noise,
                        float* out, void* stream);
+
+/* No reference counterpart (the reference decodes its noise file anew for every sample,
+ * utils/reader.py:323).  The mean square of every clip of a noise bank -- the rms_db(noise) of
+ * utils/reader.py:329 -- is computed on the first augmented call that sees the bank and kept while
+ * later calls pass the same `noise` / `noise_offsets` pointers and `n_noise`.  A caller that
+ * rewrites a bank IN PLACE (same pointers, new samples) calls this before the next augmented
+ * call; a new allocation needs nothing. */
+int wfe_noise_bank_changed(wfe_handle h);
 
 /* The same two calls on 16-bit PCM as it lies in a WAV file, replacing the
  * decode-to-float32 and mono mix-down of CustomDataset._get_list_data

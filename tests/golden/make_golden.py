@@ -218,6 +218,38 @@ def reverb_goldens():
     print("reverb goldens:", len(out), "arrays")
 
 
+SPEED2_CONFIG = [
+    {"type": "speed", "params": {"min_speed_rate": 0.9, "max_speed_rate": 1.1, "num_rates": 3}, "prob": 1.0},
+    {"type": "shift", "params": {"min_shift_ms": -5, "max_shift_ms": 5}, "prob": 1.0},
+    # a second speed entry (utils/reader.py:248-254 applies every one; its rates are the FIRST entry's:
+    # self.speed_rates is built once)
+    {"type": "speed", "params": {"min_speed_rate": 0.5, "max_speed_rate": 0.7, "num_rates": 2}, "prob": 1.0},
+    {"type": "volume", "params": {"min_gain_dBFS": -15, "max_gain_dBFS": 15}, "prob": 1.0},
+]
+
+
+def speed2_goldens():
+    """A config with TWO speed entries, run by the reference's own augment() (no noise / reverb: the
+    chain is index arithmetic and single float32 roundings, so the outputs pin the GPU chain bit for bit)."""
+    CustomDataset = _reference_dataset_class()
+    out = {"config_json": np.frombuffer(json.dumps(SPEED2_CONFIG).encode(), dtype=np.uint8)}
+    ds = object.__new__(CustomDataset)
+    ds.augment_configs = json.loads(json.dumps(SPEED2_CONFIG))
+    ds.noise_files, ds.rir_files, ds.speed_rates = [], [], None
+    n_two = 0
+    for s in range(8):
+        random.seed(60 + s)
+        src = (0.1 * np.random.default_rng(800 + s).standard_normal(9000 + 1111 * s)).astype(np.float32)
+        res, sr = ds.augment(src.copy(), 16000)
+        assert sr == 16000 and res.dtype == np.float32
+        out[f"chain_{s}"] = res
+        out[f"chain_{s}_next_random"] = np.asarray(random.random())
+        n_two += int(len(res) != len(src))
+    assert list(ds.speed_rates) == [0.9, 1.0, 1.1]
+    np.savez_compressed(os.path.join(HERE, "speed2_golden.npz"), **out)
+    print("two-speed goldens:", len(out), "arrays;", n_two, "of 8 change length")
+
+
 def dataset_goldens():
     """The reference's CustomDataset end to end on dataset/test.wav: manifests written by the
     reference's own DatasetWriter (utils/binary.py:9-35), items from its __getitem__
@@ -327,7 +359,7 @@ def dataset_goldens():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["logmel", "augment", "reverb", "dataset"]
+    which = sys.argv[1:] or ["logmel", "augment", "reverb", "dataset", "speed2"]
     if "logmel" in which:
         logmel_goldens()
     if "augment" in which:
@@ -336,3 +368,5 @@ if __name__ == "__main__":
         reverb_goldens()
     if "dataset" in which:
         dataset_goldens()
+    if "speed2" in which:
+        speed2_goldens()

@@ -145,6 +145,39 @@ def test_noise_gains_do_not_depend_on_buffer_alignment(fe):
     assert np.abs(outs[0][0]).max() > 0
 
 
+def test_noise_mean_squares_cache_follows_the_bank(fe):
+    """The handle keeps the mean squares of the last noise bank (wfe_noise_bank_changed, include/wfe.h).  A new
+    NoiseBank at a reused device address, and a bank rewritten in place, must both be seen."""
+    from wfe_amd import _lib
+    from wfe_amd.frontend import HipFrontEnd, NoiseBank, pack_ragged
+    x = [cases.bench_clip(20, 40000), cases.bench_clip(21, 52345)]
+    flat, off, lens = pack_ragged(x, fe.device)
+    plans = [[(_lib.AUG_NOISE, 0, 0, 15, 0.0)], [(_lib.AUG_NOISE, 1, 0, 25, 0.0)]]
+    quiet = [0.01 * cases.noise_clip(0, 1.0), 0.01 * cases.noise_clip(1, 1.0)]
+    loud = [2.0 * cases.noise_clip(2, 1.0), 3.0 * cases.noise_clip(3, 1.0)]
+
+    def fresh(bank):                                   # a handle that has never seen another bank
+        f2 = HipFrontEnd(n_mel=80, device=0)
+        out, _ = f2.augment_waveform(flat, lens, plans, NoiseBank(bank, f2.device), n_samples=53000, offsets=off)
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+    want_quiet, want_loud = fresh(quiet), fresh(loud)
+    assert not np.array_equal(want_quiet, want_loud)
+    nb = NoiseBank(quiet, fe.device)
+    addr = nb.data.data_ptr()
+    got, _ = fe.augment_waveform(flat, lens, plans, nb, n_samples=53000, offsets=off)
+    assert np.array_equal(got.cpu().numpy(), want_quiet)
+    del nb, got
+    nb2 = NoiseBank(loud, fe.device)                   # torch's allocator usually hands out the same address again
+    got, _ = fe.augment_waveform(flat, lens, plans, nb2, n_samples=53000, offsets=off)
+    assert np.array_equal(got.cpu().numpy(), want_loud), ("stale mean squares", nb2.data.data_ptr() == addr)
+    # rewritten in place: the caller says so (raw C ABI: wfe_noise_bank_changed; here: a new serial)
+    nb2.data.copy_(torch.from_numpy(np.concatenate(quiet)).to(fe.device))
+    nb2.serial = NoiseBank._next_serial()
+    got, _ = fe.augment_waveform(flat, lens, plans, nb2, n_samples=53000, offsets=off)
+    assert np.array_equal(got.cpu().numpy(), want_quiet)
+
+
 def test_truncation_and_fused_logmel(fe):
     """Augmented waveform -> pad/trim -> log-mel in ONE fused launch equals the CPU
     oracle run on the oracle-augmented waveform (config 3 shape, 30 s clips)."""
@@ -377,7 +410,8 @@ def test_contiguous_staging_matches_gather_form(fe, monkeypatch):
         assert not wav[i, kk:].any()
 
 
-def test_full_batch_augment_properties(fe):
+@pytest.mark.parametrize("n_mel", [80, 128])
+def test_full_batch_augment_properties(fe, n_mel):
     """BASELINE config 3 size (batch 256 x 30 s, noise -> speed -> shift -> volume drawn as bench.py --augment
     draws them): size-independent properties.  (1) Every row of the batch equals the same utterance and plan
     run in a batch of 8 (bits: the gains come from fixed-partition sums, so they do not depend on the batch).
@@ -392,6 +426,9 @@ def test_full_batch_augment_properties(fe):
         {"type": "shift", "params": {"min_shift_ms": -5, "max_shift_ms": 5}, "prob": 1.0},
         {"type": "volume", "params": {"min_gain_dBFS": -15, "max_gain_dBFS": 15}, "prob": 1.0},
     ]
+    if n_mel != fe.n_mel:
+        from wfe_amd.frontend import HipFrontEnd
+        fe = HipFrontEnd(n_mel=n_mel, device=0)
     B, K = 256, 8
     bank = [cases.noise_clip(j, 10.0) for j in range(4)]
     planner = AugmentPlanner(cfg, [len(b) for b in bank])
@@ -415,7 +452,7 @@ def test_full_batch_augment_properties(fe):
     for s in range(2):
         aug, _, _ = oa.augment(base[s].copy(), 16000, cfg, random.Random(900 + s), bank)
         want.append(aug)
-    ref = ol.logmel_f32(want, n_mel=80)
+    ref = ol.logmel_f32(want, n_mel=n_mel)
     err = np.abs(solo[:2].cpu().numpy() - ref).max()
     assert err <= 1e-4, err
 

@@ -61,14 +61,22 @@ def test_collator_in_a_dataloader_worker_raises_with_the_reason(monkeypatch):
         col([item])
 
 
-def test_config_with_two_speed_entries_is_refused_once(tmp_path):
+def test_config_with_two_speed_entries_is_accepted(tmp_path):
+    """utils/reader.py:248-254 applies every speed entry; the device chain interpolates once, so the planner
+    emits both SPEED ops and split_stages cuts the chain in front of the second (round 3; refused before)."""
+    from wfe_amd import _lib
+    from wfe_amd.augment import split_stages
     mf = tmp_path / "list.json"
     mf.write_text("")
     cfg = tmp_path / "aug.json"
-    speed = {"type": "speed", "prob": 1.0, "params": {"min_speed_rate": 0.9, "max_speed_rate": 1.1, "num_rates": 3}}
+    speed = {"type": "speed", "prob": 1.0, "params": {"min_speed_rate": 0.9, "max_speed_rate": 1.1, "num_rates": 2}}
     cfg.write_text(json.dumps([speed, speed]))
-    with pytest.raises(NotImplementedError, match="more than one 'speed' entry"):
-        wd.CustomDataset(str(mf), stubs.StubProcessor(), augment_config_path=str(cfg))
-    cfg.write_text(json.dumps([speed]))
     ds = wd.CustomDataset(str(mf), stubs.StubProcessor(), augment_config_path=str(cfg))
     assert isinstance(ds.clip_set, wd.ClipSet)
+    ops, n = ds.planner.draw(16000, 16000, __import__("random").Random(3))
+    assert [o[0] for o in ops] == [_lib.AUG_SPEED, _lib.AUG_SPEED] and n == ops[-1][1]
+    st = split_stages(ops, 16000, 16000, 16000)
+    assert len(st) == 2 and st[0]["post"] == ("pass", 0) and st[1]["len_in"] == st[0]["len_out"] == ops[0][1]
+    with pytest.raises(ValueError, match="at most one SPEED op"):         # a DEVICE chain still holds one
+        from wfe_amd.frontend import HipFrontEnd
+        HipFrontEnd.validate_plans([ops], None)

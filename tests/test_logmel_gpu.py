@@ -126,11 +126,12 @@ def test_argument_errors(fes):
     assert empty.shape == (0, 80, 3000)
 
 
-def test_full_batch_properties(fes):
-    """BASELINE config 2 size (batch 256 x 30 s): size-independent properties --
-    every row equals the same clip run alone, outputs lie in [max-2, max], and
-    permuting the batch permutes the output."""
-    fe = fes[80]
+@pytest.mark.parametrize("n_mel", [80, 128])
+def test_full_batch_properties(fes, n_mel):
+    """BASELINE config 2 size (batch 256 x 30 s; 128 mel = the kernel instantiation of configs 4 and 5):
+    size-independent properties -- every row equals the same clip run alone, outputs lie in
+    [max-2, max], and permuting the batch permutes the output."""
+    fe = fes[n_mel]
     B = 256
     base = np.stack([cases.bench_clip(s) for s in range(8)])
     idx = np.arange(B) % 8
@@ -143,5 +144,8 @@ def test_full_batch_properties(fes):
     mx = out.amax(dim=(1, 2))
     mn = out.amin(dim=(1, 2))
     assert bool(((mx - mn) <= 2.0 + 1e-6).all())
-    want = ol.logmel_f32(list(base[:2]), n_mel=80)
+    want = ol.logmel_f32(list(base[:2]), n_mel=n_mel)
     assert np.abs(solo[:2].cpu().numpy() - want).max() <= TOL
+    # the clamp against the float64 statement of HF:160-165 on whole rows: max(v, max - 8), then (v + 4) / 4
+    ref64 = np.stack([ol.logmel_f64(base[i], n_mel=n_mel) for i in range(2)])
+    assert np.abs(solo[:2].cpu().numpy() - ref64).max() <= TOL

@@ -151,3 +151,42 @@ def test_specaug_gate_sequence_matches_reference(g_dataset, monkeypatch):
     fired = [bool(ds[rep % len(ds)]["specaug"]) for rep in range(8)]
     assert fired == meta["specaug_item_fired"] and any(fired) and not all(fired)
     assert random.random() == meta["specaug_item_next_random"]
+
+
+# ---- a config with TWO speed entries (utils/reader.py:248-254), reference outputs in speed2_golden.npz
+@pytest.fixture(scope="module")
+def g_speed2():
+    return np.load(os.path.join(cases.GOLDEN, "speed2_golden.npz"))
+
+
+def test_two_speed_entries_oracle_and_planner_match_reference(g_speed2):
+    """The oracle restatement reproduces the reference's augment() bit for bit on a config with two speed
+    entries (the second entry draws from the FIRST entry's rates: speed_rates is built once), the planner
+    consumes the same random stream and predicts the same lengths, and every chain with two speed changes
+    is split into stages of at most one each."""
+    from wfe_amd import _lib
+    from wfe_amd.augment import split_stages
+    cfg = json.loads(bytes(g_speed2["config_json"]).decode())
+    planner = AugmentPlanner(cfg)
+    speed_rates = None
+    two = 0
+    for s in range(8):
+        src = (0.1 * np.random.default_rng(800 + s).standard_normal(9000 + 1111 * s)).astype(np.float32)
+        want = g_speed2[f"chain_{s}"]
+        rnd = random.Random(60 + s)
+        if speed_rates is None:
+            speed_rates = np.linspace(0.9, 1.1, 3, endpoint=True)        # reader.py:249-252: from the first entry
+        got, _, _ = oa.augment(src.copy(), 16000, cfg, rnd, [], speed_rates=speed_rates)
+        assert np.array_equal(got, want), s
+        assert rnd.random() == float(g_speed2[f"chain_{s}_next_random"])
+        rnd = random.Random(60 + s)
+        ops, n = planner.draw(len(src), 16000, rnd)
+        assert rnd.random() == float(g_speed2[f"chain_{s}_next_random"]) and n == len(want)
+        stages = split_stages(ops, len(src), 16000, 16000)
+        n_speed = sum(1 for o in ops if o[0] == _lib.AUG_SPEED)
+        assert len(stages) == max(1, n_speed)
+        assert all(sum(1 for o in st["ops"] if o[0] == _lib.AUG_SPEED) <= 1 for st in stages)
+        assert stages[0]["len_in"] == len(src) and stages[-1]["len_out"] == len(want) and stages[-1]["post"] is None
+        assert all(st["post"] == ("pass", 0) for st in stages[:-1])
+        two += int(n_speed == 2)
+    assert two >= 2

@@ -128,3 +128,45 @@ def test_specaug_through_collator_matches_reference(g_dataset, monkeypatch):
             assert not want.any() and not got[rep].any()
         else:
             assert np.abs(got[rep][:, keep] - want).max() <= TOL, rep
+
+
+@pytest.fixture(scope="module")
+def g_speed2():
+    return np.load(os.path.join(cases.GOLDEN, "speed2_golden.npz"))
+
+
+def test_two_speed_entries_match_reference_augment(g_speed2):
+    """A config with two speed entries (utils/reader.py:248-254 applies every one): the staged execution --
+    [chain with the first speed change -> waveform] then [chain with the second -> waveform / log-mel] --
+    against the reference's own augment() outputs.  No noise in this chain, so the waveform is BIT-EXACT;
+    the collator's log-mel of it is within the log-mel tolerance."""
+    from wfe_amd import data as wd
+    from wfe_amd.augment import AugmentPlanner, split_stages
+    from wfe_amd.frontend import HipFrontEnd
+    cfg = json.loads(bytes(g_speed2["config_json"]).decode())
+    planner = AugmentPlanner(cfg)
+    fe = HipFrontEnd(n_mel=80, device=0)
+    items, want = [], []
+    for s in range(8):
+        src = (0.1 * np.random.default_rng(800 + s).standard_normal(9000 + 1111 * s)).astype(np.float32)
+        ops, n = planner.draw(len(src), 16000, random.Random(60 + s))
+        w = g_speed2[f"chain_{s}"]
+        assert n == len(w)
+        # the waveform, stage by stage, through the same entry point the collator's staging uses
+        wav = torch.from_numpy(src).to(fe.device)[None]
+        lens = torch.tensor([len(src)], dtype=torch.int32, device=fe.device)
+        for st in split_stages(ops, len(src), 16000, 16000):
+            assert st["post"] in (None, ("pass", 0))
+            if st["ops"]:
+                wav, lens = fe.augment_waveform(wav, lens, [st["ops"]], None, n_samples=(st["len_out"] + 3) // 4 * 4)
+        torch.cuda.synchronize()
+        assert int(lens[0]) == len(w)
+        got = wav[0, :len(w)].cpu().numpy()
+        assert np.array_equal(got, w), (s, ops, np.abs(got - w).max())
+        items.append({"waveform": src, "aug_ops": ops, "labels": [1], "id": str(s), "sample_rate": 16000, "target_rate": 16000})
+        want.append(w)
+    coll = wd.DataCollatorSpeechSeq2SeqWithPadding(processor=stubs.StubProcessor(80))
+    got = coll(items)["input_features"].numpy()
+    ref = ol.logmel_f32(want, n_mel=80)
+    err = np.abs(got - ref).reshape(len(items), -1).max(axis=1)
+    assert (err <= TOL).all(), err

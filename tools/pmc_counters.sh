@@ -6,7 +6,7 @@ set -u
 export TMPDIR=/tmp
 D=$1; C=$2; shift 2
 mkdir -p "$D"
-timeout -s KILL 120 rocprofv3 --pmc $C --output-format csv -d "$D/pmc" -- python3 bench.py --steps 5 --warmup 1 --prewarm-ms 50 --no-cpu-baseline "$@" > "$D/pmc.log" 2>&1 || { tail -n 5 "$D/pmc.log"; exit 1; }
+timeout -s KILL 120 rocprofv3 --pmc $C --output-format csv -d "$D/pmc" -- python3 bench.py --steps 5 --warmup 1 --prewarm-ms 50 --no-cpu-baseline --no-also "$@" > "$D/pmc.log" 2>&1 || { tail -n 5 "$D/pmc.log"; exit 1; }
 python3 - "$D" <<'PY'
 import csv, glob, sys, collections
 d = sys.argv[1]

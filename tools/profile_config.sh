@@ -16,7 +16,7 @@ for a in "$@"; do
   prev=$a
 done
 cp profiles/traffic.json /tmp/traffic_before.json
-python3 tools/update_traffic.py "$D" --n-mel "$NM" $AUG --lengths "$LEN" --source "round 2, profiles/round2_$L.txt" > "gpurun_out/traffic_$L.json" 2>&1
+python3 tools/update_traffic.py "$D" --n-mel "$NM" $AUG --lengths "$LEN" --source "round 3, profiles/round3_$L.txt" > "gpurun_out/traffic_$L.json" 2>&1
 cp /tmp/traffic_before.json profiles/traffic.json
 rm -rf "$D"
 echo "profiled $L"

@@ -11,9 +11,9 @@ shift || true
 mkdir -p "$D"
 cd "$R" || exit 1
 timeout -k 10 300 python3 -u bench.py "$@" > "$D/bench.json" 2> "$D/bench.err" || exit 1
-timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -- python3 bench.py --no-cpu-baseline "$@" > "$D/trace.log" 2>&1 || exit 1
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d "$D/pmc_sq" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline "$@" > "$D/pmc_sq.log" 2>&1 || exit 1
-timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$D/pmc_fetch" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline "$@" > "$D/pmc_fetch.log" 2>&1 || exit 1
-timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$D/pmc_write" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline "$@" > "$D/pmc_write.log" 2>&1 || exit 1
-timeout -s KILL 120 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INST_CYCLES_VMEM_RD TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$D/pmc_lds" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline "$@" > "$D/pmc_lds.log" 2>&1 || exit 1
+timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$D/trace" -- python3 bench.py --no-cpu-baseline --no-also "$@" > "$D/trace.log" 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --output-format csv -d "$D/pmc_sq" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-also "$@" > "$D/pmc_sq.log" 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$D/pmc_fetch" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-also "$@" > "$D/pmc_fetch.log" 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$D/pmc_write" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-also "$@" > "$D/pmc_write.log" 2>&1 || exit 1
+timeout -s KILL 120 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INST_CYCLES_VMEM_RD TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$D/pmc_lds" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-also "$@" > "$D/pmc_lds.log" 2>&1 || exit 1
 echo done

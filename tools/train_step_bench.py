@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--steps", type=int, default=12)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--modes", default="gpu,cpu")
+    ap.add_argument("--modes", default="none,gpu,gpu+prefetch,cpu")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -117,14 +117,26 @@ def main():
     opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4)
     proc = stubs.StubProcessor(n_mel=n_mel)
     for mode in args.modes.split(","):
-        # GPU mode keeps the features on the device (no pinning of CUDA tensors); the CPU mode is the reference's
-        coll = wd.DataCollatorSpeechSeq2SeqWithPadding(processor=proc, device_output=(mode == "gpu"))
-        ds = Utterances((args.steps + args.warmup) * args.batch * world, n_mel, mode)
+        # modes: "gpu" = the MI355X front end in the collator, serial with the step (num_workers=0);
+        # "gpu+prefetch" = the same, iterated one batch ahead on a thread (wfe_amd.data.PrefetchIterator, what
+        # wfe_amd.launch installs); "cpu" = the reference's structure (extractor per item in 8 workers);
+        # "none" = no input pipeline at all (one precomputed batch reused): the step's own time
+        gpu = mode.startswith("gpu")
+        # GPU modes keep the features on the device (no pinning of CUDA tensors); the CPU mode is the reference's
+        coll = wd.DataCollatorSpeechSeq2SeqWithPadding(processor=proc, device_output=gpu,
+                                                       private_handle=(mode == "gpu+prefetch"))
+        ds = Utterances((args.steps + args.warmup) * args.batch * world, n_mel, "cpu" if mode == "cpu" else "gpu")
         sampler = torch.utils.data.distributed.DistributedSampler(ds, world, rank, shuffle=False) if world > 1 else None
         loader = torch.utils.data.DataLoader(ds, batch_size=args.batch, sampler=sampler, collate_fn=coll,
                                              num_workers=8 if mode == "cpu" else 0, pin_memory=(mode == "cpu"),
                                              persistent_workers=False)
         it = iter(loader)
+        if mode == "gpu+prefetch":
+            it = wd.PrefetchIterator(it, device=local)
+        elif mode == "none":
+            one = next(it)
+            one = {k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in one.items()}
+            it = iter(lambda: one, None)
         t_data = t0 = 0.0
         for step in range(args.steps + args.warmup):
             if step == args.warmup:

@@ -15,7 +15,7 @@ struct Resolved {
   float b;
 };
 
-constexpr int kTileStats = 12;   // floats kernel 1 leaves per 64-frame tile for kernel 2
+constexpr int kTileStats = 36;   // floats kernel 1 leaves per 64-frame tile for kernel 2: [wave 4][mel tile 8] minima, [wave 4] maxima
 
 // What the resolve pass (resolve_utterance) leaves per utterance for kernel 1: the chain's geometry, and (in `cops`)
 // its ops compiled with their resolved scalars -- kernel 1 then needs two load round trips to
@@ -55,7 +55,7 @@ struct FrontArgs {
   // output
   float* out;                    // (B, n_mel, T) log10 mel power, or (B, 201, T) power
   int out_kind;                  // log-mel element type: 0 float32, 1 float16, 2 bfloat16 (out then points to 2-byte elements)
-  float* tile_stats;             // (B x 64-frame tiles x kTileStats): log10 mel minima [frame group 4][2], maxima [wave 4]
+  float* tile_stats;             // (B x 64-frame tiles x kTileStats): minima [wave 4][mel tile 8], maxima [wave 4], in the stored scale
   // augmentation (AUG kernels only)
   const wfe_aug_op* ops;
   const int* op_begin;

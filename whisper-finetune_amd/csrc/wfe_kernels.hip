@@ -842,10 +842,14 @@ __device__ __forceinline__ bool stage_contiguous(const Chain& c, const ChainHead
   // R rows (256 lanes x 4 samples) of the source from sample s0 on, and the noise that meets them.  A lane
   // whose four noise samples would straddle the end of the clip reads the clip's last four instead and is
   // counted in `split`.
+  // `need` (uniform): how many samples from s0 on the caller will read.  Loads beyond them are out of the buffer's
+  // range -- they return 0 and fetch nothing (round 3: a chunk of a slowed-down utterance needs 4 of its 5 rows,
+  // the last row of a tile without SPEED 240 of its 1024 samples) -- with no branch in the load sequence.
   bool split = false;
-  auto fetch = [&](auto& X, auto& NZ, int s0, auto rows) {
+  auto fetch = [&](auto& X, auto& NZ, int s0, int need, auto rows) {
     constexpr int R = decltype(rows)::value;
-    const __amdgpu_buffer_rsrc_t rx = f32_rsrc(c.src.w, s0, (long long)L0 - s0);
+    const long long left = (long long)L0 - s0;
+    const __amdgpu_buffer_rsrc_t rx = f32_rsrc(c.src.w, s0, left < need ? left : (long long)need);
 #pragma unroll
     for (int i = 0; i < R; ++i) X[i] = buf_f32x4(rx, t16 + 4096 * i);
     if (NOISE) {
@@ -855,13 +859,15 @@ __device__ __forceinline__ bool stage_contiguous(const Chain& c, const ChainHead
         const unsigned top = ln4 - 16u;
 #pragma unroll
         for (int i = 0; i < R; ++i) {
-          split = split || mb > top;
-          NZ[i] = buf_f32x4(rn, (int)min(mb, top));
+          const bool wanted = 1024 * i < need;      // (uniform) whole rows beyond `need`: an offset outside the clip
+          split = split || (wanted && mb > top);
+          NZ[i] = buf_f32x4(rn, wanted ? (int)min(mb, top) : 0x7ffffff0);
           mb += 4096u;
           mb = min(mb, mb - ln4);                   // ln >= 1024: at most one wrap per row
         }
       } else {                                      // the slice noise[start : start + L0]
-        const __amdgpu_buffer_rsrc_t rn = f32_rsrc(clip, (long long)s0 + start, (long long)ln - s0 - start);
+        const long long nleft = (long long)ln - s0 - start;
+        const __amdgpu_buffer_rsrc_t rn = f32_rsrc(clip, (long long)s0 + start, nleft < need ? nleft : (long long)need);
 #pragma unroll
         for (int i = 0; i < R; ++i) NZ[i] = buf_f32x4(rn, t16 + 4096 * i);
       }
@@ -891,7 +897,7 @@ __device__ __forceinline__ bool stage_contiguous(const Chain& c, const ChainHead
 #pragma unroll
     for (int r = 0; r < 5; ++r) pb[r] = pad_q(4 * tid + 1024 * r);      // pad_q(q + 5120) = pad_q(q) + 5152
     f32x4 X[kImageVecs], NZ[kImageVecs];
-    fetch(X, NZ, cur0, std::integral_constant<int, kImageVecs>{});
+    fetch(X, NZ, cur0, kBlockSamples, std::integral_constant<int, kImageVecs>{});
     constexpr int kTailLanes = (kBlockSamples - 1024 * (kImageVecs - 1)) / 4;        // 60 lanes in the last row
 #pragma unroll
     for (int row = 0; row < kImageVecs; ++row) {
@@ -917,19 +923,20 @@ __device__ __forceinline__ bool stage_contiguous(const Chain& c, const ChainHead
     if (row < kImageRows - 1 || tid < kLastRowLanes) lds[pb[row % 5] + 1288 * (row / 5)] = v;
   };
   f32x4 X[kSrcVecs], NZ[kSrcVecs];
-  struct Span { int lo, hi, jlo; };
+  struct Span { int lo, hi, jlo, need; };
   auto span_of = [&](int k, int out_rows) {
     const int first = cur0 + 256 * kChunkRows * k;
     Span s;
     s.lo = uni(min(max(first, 0), L1 - 1));
     s.hi = uni(min(max(first + 256 * out_rows - 1, 0), L1 - 1));
     s.jlo = uni(src_of(s.lo));                      // (src_of(hi) + 1 - jlo < kSrcFloats by the check on step above)
+    s.need = uni(src_of(s.hi)) - s.jlo + 2;         // np.interp reads source samples jlo .. src_of(hi) + 1
     return s;
   };
   constexpr int kChunks = (kImageRows + kChunkRows - 1) / kChunkRows;       // 3
   Span nxt = span_of(0, kChunkRows);
   tk.mark(0);
-  fetch(X, NZ, nxt.jlo, std::integral_constant<int, kSrcVecs>{});
+  fetch(X, NZ, nxt.jlo, nxt.need, std::integral_constant<int, kSrcVecs>{});
 #pragma unroll
   for (int k = 0; k < kChunks; ++k) {
     const Span s = nxt;
@@ -945,7 +952,7 @@ __device__ __forceinline__ bool stage_contiguous(const Chain& c, const ChainHead
     tk.mark(1);
     if (k + 1 < kChunks) {                          // the next chunk's rows travel under this chunk's interpolation
       nxt = span_of(k + 1, (k + 2 < kChunks) ? kChunkRows : kImageRows - kChunkRows * (k + 1));
-      fetch(X, NZ, nxt.jlo, std::integral_constant<int, kSrcVecs>{});
+      fetch(X, NZ, nxt.jlo, nxt.need, std::integral_constant<int, kSrcVecs>{});
     }
     __syncthreads();
     tk.mark(2);
@@ -1200,7 +1207,7 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
         // clamp, so kernel 2 (which knows the utterance maximum) writes its final value
         // once.  -inf marks the tile as silent; real minima are >= -10.
         if (tid < kTileStats)
-          a.tile_stats[((long long)b * nblk + tx) * kTileStats + tid] = tid < 8 ? -INFINITY : -1.5f;      // (g(-10): its maximum)
+          a.tile_stats[((long long)b * nblk + tx) * kTileStats + tid] = tid < 32 ? -INFINITY : -1.5f;     // (g(-10): its maximum)
       }
       return;
     }
@@ -1676,7 +1683,11 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
     return __builtin_fmaxf(__builtin_fmaf(__builtin_amdgcn_logf(pw), 0.25f * 0.30102999566398120f, 1.0f), -1.5f);
 #endif
   };
-  float pmax = -INFINITY, pmin = INFINITY;
+  // Per wave: ONE maximum, and a minimum per MEL TILE (16 rows) -- round 3: kernel 2 then looks at the 16-frame x
+  // 16-row blocks that hold a value below the floor (a few percent of them) instead of at whole half tiles.
+  float pmax = -INFINITY, lmin[8];
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) lmin[mt] = INFINITY;
 #pragma unroll
   for (int mt = 0; mt < NMT; ++mt) {
     float hi = __builtin_fmaxf(__builtin_fmaxf(m[mt][0], m[mt][1]), m[mt][2]);      // v_max3_f32
@@ -1692,16 +1703,46 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
       }
     }
     pmax = __builtin_fmaxf(__builtin_fmaxf(pmax, hi), hi3);
-    pmin = __builtin_fminf(__builtin_fminf(pmin, lo), lo3);
+    lmin[mt] = frame_ok ? __builtin_fminf(lo, lo3) : INFINITY;
   }
 #if !(WFE_ABLATE & 16)
   pmax = wave_reduce<true>(frame_ok ? pmax : -INFINITY);
-  pmin = wave_reduce<false>(frame_ok ? pmin : INFINITY);
 #endif
+  // The 8 minima over the 64 lanes by a transposing butterfly: each exchange halves the values a lane carries
+  // (a lane keeps the half its own bit selects and takes the partner's minimum of the same half), so the whole
+  // reduction is 7 + 1 + 2 min instructions and 14 selects instead of 8 separate wave reductions.  Afterwards
+  // lane l holds the wave's minimum of mel tile 4 b0 + 2 b1 + b2 (b = bits of l).
+  float red;
+  {
+    const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+    float u[4], w2[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float keep = b0 ? lmin[i + 4] : lmin[i], send = b0 ? lmin[i] : lmin[i + 4];
+      u[i] = __builtin_fminf(keep, dpp_mov<0xB1>(send));        // quad_perm [1,0,3,2]: lane ^ 1
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float keep = b1 ? u[i + 2] : u[i], send = b1 ? u[i] : u[i + 2];
+      w2[i] = __builtin_fminf(keep, dpp_mov<0x4E>(send));       // quad_perm [2,3,0,1]: lane ^ 2
+    }
+    {
+      const float keep = b2 ? w2[1] : w2[0], send = b2 ? w2[0] : w2[1];
+      red = __builtin_fminf(keep, dpp_mov<0x124>(send));        // row_ror:4: the sender's bit 2 is the opposite one
+    }
+    red = __builtin_fminf(red, dpp_mov<0x128>(red));            // row_ror:8: the whole row of 16
+    // across the four rows of 16: the swaps leave (own row, other row) in the two results
+    const unsigned ur = __float_as_uint(red);
+    const auto s16 = __builtin_amdgcn_permlane16_swap(ur, ur, false, false);
+    red = __builtin_fminf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+    const unsigned us = __float_as_uint(red);
+    const auto s32 = __builtin_amdgcn_permlane32_swap(us, us, false, false);
+    red = __builtin_fminf(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
+  }
   // statistics in the STORED scale (g): g of the extreme powers = the extremes of the stored values, exactly
   // (a wave without a valid frame leaves -inf / +inf, as before)
   const float wmax = pmax == -INFINITY ? -INFINITY : g_of(pmax);
-  const float wmin = pmin == INFINITY ? INFINITY : g_of(pmin);
+  const float wmin = red == INFINITY ? INFINITY : g_of(red);
 #pragma unroll
   for (int mt = 0; mt < NMT; ++mt)
 #pragma unroll
@@ -1709,11 +1750,11 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
       const int mel = 16 * mt + 4 * kk + r;
       tile[mel * kTileStride + wave * 16 + jl] = g_of(m[mt][r]);
     }
-  if (lane == 0) {
+  {
+    // [wave 4][mel tile 8] minima, then [wave 4] maxima: plain stores, kernel 2 reduces the maxima (no atomics, no zeroing)
     float* st = a.tile_stats + ((long long)b * nblk + tx) * kTileStats;
-    st[2 * wave] = wmin;                 // both entries of the frame group's pair
-    st[2 * wave + 1] = wmin;
-    st[8 + wave] = wmax;                 // plain stores: kernel 2 reduces the maxima (no atomics, no zeroing)
+    if (lane < 8) st[8 * wave + 4 * (lane & 1) + (lane & 2) + ((lane >> 2) & 1)] = wmin;
+    if (lane == 0) st[32 + wave] = wmax;
   }
   __syncthreads();
   float* __restrict__ lo = a.out + (long long)b * a.n_mel * T + t0;
@@ -1771,111 +1812,106 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
 
 // ------------------------------------------------------------- kernel 2
 // log_spec = maximum(log_spec, max - 8.0); (log_spec + 4.0) / 4.0   (HF:160-165).
-// Kernel 1 already stored g(v) = (v + 4) / 4 and the minimum v of each of its
-// workgroups; g is monotone, so the result is max(stored, g(max - 8)) bit for bit, and
-// a workgroup's (n_mel x 64) tile needs touching only when its minimum is below
-// max - 8.  One workgroup here per workgroup of kernel 1: most exit after 5 loads.
+// Kernel 1 already stored g(v) = (v + 4) / 4 and, per 64-frame tile, the maximum of each of its waves
+// (16 frames) and the minimum of each wave's 16-row mel tiles, all in the stored scale; g is monotone, so the
+// result is max(stored, g(max) - 2) bit for bit, and a (16 frames x 16 mel rows) block needs touching only when
+// its minimum is below that floor.  kClampParts workgroups per utterance, each walking every kClampParts-th tile
+// (round 3: one workgroup per tile was 12 032 workgroups that mostly exit -- 0.016 ms of dispatch -- and a
+// half tile of ALL mel rows was read for one quiet row: 383 MB per 256 x 30 s at 128 mel).
+constexpr int kClampParts = 8;
 __global__ __launch_bounds__(256) void clamp_kernel(float* __restrict__ out, int out_kind,
                                                     const float* __restrict__ tile_stats, int n_mel, int T) {
   __shared__ float sh[4];
   const int b = blockIdx.y;
-  const int nblk = gridDim.x;
-  const int tx = tile_of_block(nblk);          // (the silent tiles this kernel writes are as unevenly spread as kernel 1's live ones)
+  const int nblk = (T + kBlockFrames - 1) / kBlockFrames;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* __restrict__ stats = tile_stats + (long long)b * nblk * kTileStats;
   // log_spec.max() of the utterance (HF:161): the maximum of the per-wave maxima kernel 1 left
   float gmax = -INFINITY;
-  for (int i = threadIdx.x; i < nblk * 4; i += 256)
-    gmax = fmaxf(gmax, tile_stats[((long long)b * nblk + (i >> 2)) * kTileStats + 8 + (i & 3)]);
+  for (int i = tid; i < nblk * 4; i += 256) gmax = fmaxf(gmax, stats[(i >> 2) * kTileStats + 32 + (i & 3)]);
   gmax = wave_reduce<true>(gmax);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = gmax;
+  if (lane == 0) sh[wv] = gmax;
   __syncthreads();
   gmax = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
   // the statistics are in the stored scale g(v) = (v + 4) / 4: g(max - 8) = g(max) - 2
   const float floor_g = gmax - 2.0f;
-  const float* bm = tile_stats + ((long long)b * nblk + tx) * kTileStats;   // [frame group 4][wave of the pair 2]
-  // decided per half tile (32 frames): two frame groups, each with the minima of its (up to two) waves
-  const int tid = threadIdx.x;
-  if (out_kind != 0) {
-    // 16-bit output: max(h, round(floor)) on the stored halves == round(max(g(v), floor))
-    const bool bf = out_kind == 2;
-    unsigned short* __restrict__ p16 =
-        reinterpret_cast<unsigned short*>(out) + (long long)b * n_mel * T + tx * kBlockFrames;
-    const bool vec16 = (T & 3) == 0 && (reinterpret_cast<uintptr_t>(p16) & 7u) == 0;
-    const unsigned hf = to16(floor_g, bf), hc = to16(fmaxf(-1.5f, floor_g), bf);
-    const float ff = from16(hf, bf);
-    for (int h = 0; h < 2; ++h) {
-      const float lowest = fminf(fminf(bm[4 * h], bm[4 * h + 1]), fminf(bm[4 * h + 2], bm[4 * h + 3]));
-      if (!(lowest < floor_g)) continue;
-      const int t0 = tx * kBlockFrames + 32 * h;
-      if (t0 >= T) continue;
-      const int frames_here = (T - t0 < 32) ? (T - t0) : 32;
-      unsigned short* __restrict__ ph = p16 + 32 * h;
-      const bool silent = lowest == -INFINITY;
-      if (vec16) {
-        for (int idx = tid; idx < n_mel * 8; idx += 256) {
-          const int mel = idx >> 3, c4 = idx & 7;
-          if (4 * c4 < frames_here) {
-            uint2* q = reinterpret_cast<uint2*>(ph + (long long)mel * T + 4 * c4);
-            uint2 v;
-            v.x = v.y = hc | (hc << 16);
-            if (silent) {
-              *q = v;
-            } else {
-              const uint2 old = *q;
-              unsigned e[4] = {old.x & 0xffffu, old.x >> 16, old.y & 0xffffu, old.y >> 16};
-#pragma unroll
-              for (int j = 0; j < 4; ++j) e[j] = (from16(e[j], bf) > ff) ? e[j] : hf;
-              v.x = e[0] | (e[1] << 16);
-              v.y = e[2] | (e[3] << 16);
-              if (v.x != old.x || v.y != old.y) *q = v;      // (only where the clamp changes something)
-            }
-          }
-        }
-      } else {
-        for (int idx = tid; idx < n_mel * 32; idx += 256) {
-          const int mel = idx >> 5, fb = idx & 31;
-          if (fb < frames_here) {
-            unsigned short* q = ph + (long long)mel * T + fb;
-            const unsigned e = *q;
-            *q = (unsigned short)(silent ? hc : ((from16(e, bf) > ff) ? e : hf));
-          }
-        }
+  const float fill = fmaxf(-1.5f, floor_g);           // a silent tile: every value is max(g(-10), g(max-8))
+  const bool bf = out_kind == 2;
+  const unsigned hf = to16(floor_g, bf), hfill = to16(fill, bf);
+  const float ff = from16(hf, bf);
+  const int n_mt = (n_mel + 15) >> 4;
+  // This workgroup's tiles are tx = blockIdx.x + kClampParts j.  Eight of them at a time: thread t looks at ONE
+  // block (tile j = t >> 5, frame group w = (t >> 3) & 3, mel tile mt = t & 7) -- all the minima in one round trip
+  // -- and each wave then walks the set bits of its own ballot (its 64 blocks = two tiles); most ballots are empty.
+  const int row = lane >> 2, c4 = lane & 3;            // a block is 16 rows x 16 frames: lane -> row, frames 4 c4 .. + 3
+  for (int j0 = 0; blockIdx.x + kClampParts * j0 < nblk; j0 += 8) {
+    const int tj = blockIdx.x + kClampParts * (j0 + (tid >> 5));
+    const int mt_t = tid & 7;
+    float lowest_t = INFINITY;
+    if (tj < nblk && mt_t < n_mt) lowest_t = stats[tj * kTileStats + (tid & 31)];
+    // Tiles kernel 1 left unwritten (silence behind a short utterance: most of a ragged batch) are filled whole,
+    // every wave 4 rows x 64 frames at a time (256-byte row segments); tiles at a ragged end of T or of an
+    // unaligned output take the block path below.
+    if (out_kind == 0 && (T & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) {
+      for (int j = 0; j < 8; ++j) {
+        const int tx = blockIdx.x + kClampParts * (j0 + j);
+        if (tx >= nblk || (tx + 1) * kBlockFrames > T) break;
+        if (stats[tx * kTileStats] != -INFINITY) continue;          // (uniform)
+        float* __restrict__ p = out + ((long long)b * n_mel) * T + tx * kBlockFrames + 4 * (tid & 15);
+        for (int mel = tid >> 4; mel < n_mel; mel += 16)
+          *reinterpret_cast<f32x4*>(p + (long long)mel * T) = f32x4{fill, fill, fill, fill};
+        if ((tid >> 5) == j) lowest_t = INFINITY;                    // done: not a block of the ballot
       }
     }
-    return;
-  }
-  float* __restrict__ p = out + (long long)b * n_mel * T + tx * kBlockFrames;
-  const bool vec = (T & 3) == 0 && (reinterpret_cast<uintptr_t>(p) & 15u) == 0;
-  for (int h = 0; h < 2; ++h) {
-    const float lowest = fminf(fminf(bm[4 * h], bm[4 * h + 1]), fminf(bm[4 * h + 2], bm[4 * h + 3]));
-    if (!(lowest < floor_g)) continue;
-    const int t0 = tx * kBlockFrames + 32 * h;
-    if (t0 >= T) continue;
-    const int frames_here = (T - t0 < 32) ? (T - t0) : 32;
-    float* __restrict__ ph = p + 32 * h;
-    const bool silent = lowest == -INFINITY;     // left unwritten by kernel 1: every value is max(g(-10), g(max-8))
-    const float c = fmaxf(-1.5f, floor_g);
-    if (vec) {
-      for (int idx = tid; idx < n_mel * 8; idx += 256) {
-        const int mel = idx >> 3, c4 = idx & 7;
-        if (4 * c4 < frames_here) {
-          f32x4* q = reinterpret_cast<f32x4*>(ph + (long long)mel * T + 4 * c4);
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(lowest_t < floor_g);
+    while (todo) {
+      const int bit = __builtin_ctzll(todo);
+      todo &= todo - 1;
+      const int t = 64 * wv + bit;                      // (uniform) the thread whose block this is
+      const int tx = blockIdx.x + kClampParts * (j0 + (t >> 5)), w = (t >> 3) & 3, mt = t & 7;
+      const float lowest = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lowest_t), bit));
+      const bool silent = lowest == -INFINITY;          // left unwritten by kernel 1
+      const int mel = 16 * mt + row, f0 = tx * kBlockFrames + 16 * w + 4 * c4;
+      if (mel >= n_mel || f0 >= T) continue;
+      const long long at = ((long long)b * n_mel + mel) * T + f0;
+      if (out_kind == 0) {
+        float* __restrict__ p = out + at;
+        if (f0 + 4 <= T && (reinterpret_cast<uintptr_t>(p) & 15u) == 0) {
+          f32x4* q4 = reinterpret_cast<f32x4*>(p);
           if (silent) {
-            *q = f32x4{c, c, c, c};
+            *q4 = f32x4{fill, fill, fill, fill};
           } else {
-            // written back only where the clamp changes something: a half tile is here because ONE of its
-            // values lies below the floor (often a single quiet mel row), the rest is read and left alone
-            const f32x4 v = *q;
+            // written back only where the clamp changes something
+            const f32x4 v = *q4;
             if (fminf(fminf(v[0], v[1]), fminf(v[2], v[3])) < floor_g)
-              *q = f32x4{fmaxf(v[0], floor_g), fmaxf(v[1], floor_g), fmaxf(v[2], floor_g), fmaxf(v[3], floor_g)};
+              *q4 = f32x4{fmaxf(v[0], floor_g), fmaxf(v[1], floor_g), fmaxf(v[2], floor_g), fmaxf(v[3], floor_g)};
           }
+        } else {
+          for (int e = 0; e < 4 && f0 + e < T; ++e) p[e] = silent ? fill : fmaxf(p[e], floor_g);
         }
-      }
-    } else {
-      for (int idx = tid; idx < n_mel * 32; idx += 256) {
-        const int mel = idx >> 5, fb = idx & 31;
-        if (fb < frames_here) {
-          float* q = ph + (long long)mel * T + fb;
-          *q = silent ? c : fmaxf(*q, floor_g);
+      } else {
+        // 16-bit output: max(h, round(floor)) on the stored halves == round(max(g(v), floor))
+        unsigned short* __restrict__ p = reinterpret_cast<unsigned short*>(out) + at;
+        if (f0 + 4 <= T && (reinterpret_cast<uintptr_t>(p) & 7u) == 0) {
+          uint2* q2 = reinterpret_cast<uint2*>(p);
+          uint2 v;
+          v.x = v.y = hfill | (hfill << 16);
+          if (silent) {
+            *q2 = v;
+          } else {
+            const uint2 old = *q2;
+            unsigned e[4] = {old.x & 0xffffu, old.x >> 16, old.y & 0xffffu, old.y >> 16};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) e[k] = (from16(e[k], bf) > ff) ? e[k] : hf;
+            v.x = e[0] | (e[1] << 16);
+            v.y = e[2] | (e[3] << 16);
+            if (v.x != old.x || v.y != old.y) *q2 = v;      // (only where the clamp changes something)
+          }
+        } else {
+          for (int e = 0; e < 4 && f0 + e < T; ++e) {
+            const unsigned old = p[e];
+            p[e] = (unsigned short)(silent ? hfill : ((from16(old, bf) > ff) ? old : hf));
+          }
         }
       }
     }
@@ -2793,7 +2829,7 @@ hipError_t launch_frontend(const FrontArgs& a, int batch, int mode, bool aug, in
 
 hipError_t launch_clamp(float* out, int out_kind, const float* tile_stats, int batch, int n_mel, int n_frames,
                         hipStream_t stream) {
-  const dim3 grid((n_frames + kBlockFrames - 1) / kBlockFrames, batch);
+  const dim3 grid(kClampParts, batch);
   hipLaunchKernelGGL(clamp_kernel, grid, dim3(256), 0, stream, out, out_kind, tile_stats, n_mel, n_frames);
   return hipGetLastError();
 }

@@ -52,6 +52,7 @@ SYMBOLS = {
     "wfe_build_resample_table": (C.c_int, [C.c_int32, C.c_int32, _P]),
     "wfe_augment_waveform": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_int64,
                                        _P, _P, C.c_int32, _P, _P, _P]),
+    "wfe_noise_bank_changed": (C.c_int, [_P]),
     "wfe_set_output_format": (C.c_int, [_P, C.c_int32]),
     "wfe_kernel_timing": (C.c_int, [_P, C.c_int32]),
     "wfe_kernel_times": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]),

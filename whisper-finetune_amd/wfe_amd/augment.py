@@ -9,7 +9,9 @@ Draw order restated from the reference:
   * config entries in file order; an entry whose ``type`` is one of speed / shift /
     volume / resample / noise / reverb draws ``random.random()`` once (also at
     prob 0.0); any other type (e.g. specaug) draws nothing here;
-  * speed:  ``random.choice(np.linspace(min, max, num))``; rate 1.0 is a no-op;
+  * speed:  ``random.choice(np.linspace(min, max, num))``; rate 1.0 is a no-op; the rates are those of the
+            FIRST speed entry that fires (``self.speed_rates`` is built once, reader.py:249-252); every
+            further speed change of one utterance starts a new STAGE (below);
   * shift:  ``random.randint(min_ms, max_ms)``; samples = int(ms * sr / 1000);
   * volume: ``random.randint(min_dB, max_dB)``; multiplier float32(10 ** (g / 20));
   * noise:  only when noise clips exist: ``random.choice(files)``,
@@ -46,8 +48,9 @@ def resampled_length(n: int, orig_sr: int, target_sr: int) -> int:
 def split_stages(ops: Sequence[Op], length: int, sample_rate: int, target_rate: int):
     """-> [{"sr", "ops", "len_in", "len_out", "post"}]: ``ops`` (device ops only) run on
     ``len_in`` samples at ``sr`` and leave ``len_out``; ``post`` is what joins the stage
-    to the next one: ("resample", new_sr), ("reverb", rir index) or None after the last
-    stage, which is always at ``target_rate`` (reader.py:157-158)."""
+    to the next one: ("resample", new_sr), ("reverb", rir index), ("pass", 0) in front of a
+    second speed change, or None after the last stage, which is always at ``target_rate``
+    (reader.py:157-158)."""
     stages, cur, sr, n = [], [], int(sample_rate), int(length)
     n_in = n
     for op in list(ops) + [(HOST_RESAMPLE, int(target_rate), 0, 0, 0.0)]:
@@ -63,6 +66,11 @@ def split_stages(ops: Sequence[Op], length: int, sample_rate: int, target_rate: 
             cur, n_in = [], n
             continue
         if op[0] == AUG_SPEED:
+            if any(o[0] == AUG_SPEED for o in cur):
+                # a second speed change (a config with several 'speed' entries, reader.py:248-254): the device
+                # chain interpolates once, so the chain so far is materialised and a new stage starts here
+                stages.append({"sr": sr, "ops": cur, "len_in": n_in, "len_out": n, "post": ("pass", 0)})
+                cur, n_in = [], n
             n = int(op[1])
         cur.append(op)
     stages.append({"sr": sr, "ops": cur, "len_in": n_in, "len_out": n, "post": None})
@@ -101,8 +109,6 @@ class AugmentPlanner:
                 if rate != 1.0:
                     if rate <= 0:
                         raise ValueError("speed rate must be > 0")
-                    if any(o[0] == AUG_SPEED for o in ops):
-                        raise NotImplementedError("more than one speed op per utterance")
                     new_len = int(n / rate)
                     ops.append((AUG_SPEED, new_len, 0, 0, 0.0))
                     n = new_len

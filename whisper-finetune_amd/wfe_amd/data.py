@@ -35,6 +35,7 @@ from typing import Any, List, Optional
 import numpy as np
 import torch
 
+from ._lib import AUG_SPEED
 from .augment import AugmentPlanner, is_host_op, split_stages
 
 try:                                    # audio decode is host I/O, outside the GPU path
@@ -300,12 +301,8 @@ class CustomDataset(torch.utils.data.Dataset):
                 self.rir_rates.append(int(sr))
             self.planner = AugmentPlanner(self.augment_configs, [len(c) for c in self.noise_clips],
                                           len(self.rir_files or []), noise_rates=self.noise_rates)
-            # The GPU chain holds one SPEED op per utterance (include/wfe.h wfe_aug_op); the reference
-            # would apply every speed entry of its config (reader.py:248-254).  A config with two of
-            # them is refused here, once and loudly, instead of failing per sample.
-            if sum(1 for cfg in self.augment_configs if cfg.get("type") == "speed") > 1:
-                raise NotImplementedError("augmentation config with more than one 'speed' entry: the GPU chain "
-                                          "supports one speed change per utterance")
+            # (a config with several 'speed' entries, reader.py:248-254: a device chain interpolates once, so every
+            # further speed change of an utterance runs as a stage of its own -- augment.split_stages)
         self.clip_set = ClipSet(self.noise_clips, self.noise_rates, self.rir_clips, self.rir_rates)
 
     @staticmethod
@@ -489,9 +486,15 @@ class DataCollatorSpeechSeq2SeqWithPadding:
     with_ids = False
 
     def __init__(self, processor: Any, device=None, device_output: Optional[bool] = None, noise_clips=None,
-                 noise_rates=None, output_dtype=None, strip_sot: Optional[bool] = None):
+                 noise_rates=None, output_dtype=None, strip_sot: Optional[bool] = None,
+                 private_handle: Optional[bool] = None):
         self.processor = processor
         self.device = device
+        # A front-end handle of this collator's own instead of the one shared with the feature extractor: for a
+        # collator that runs on the prefetch thread (install_prefetch) while the main thread may call the extractor
+        # (one host thread and one stream per handle at a time, include/wfe.h).
+        self.private_handle = (os.environ.get("WFE_PRIVATE_HANDLE", "0") == "1") if private_handle is None \
+            else bool(private_handle)
         # Leading-token handling of the training labels.  Default = the upstream project's collator: only a
         # shared ``bos_token_id`` is dropped (for Whisper tokenizers that is <|endoftext|>, which never leads
         # a row, so <|startoftranscript|> STAYS in the labels).  strip_sot=True / WFE_STRIP_SOT=1 also drops a
@@ -606,6 +609,8 @@ class DataCollatorSpeechSeq2SeqWithPadding:
                 wav, lens = fe.augment_waveform(wav, lens, plans, self._bank_for(fe, sr, plans, clip_set),
                                                 n_samples=width, offsets=off)
                 off, ch = None, 1
+            if post[0] == "pass":                          # in front of a second speed change: the waveform as it is
+                continue
             if post[0] == "resample":
                 wav, lens = fe.resample(wav, lens, sr, post[1], offsets=off, channels=ch, host_lengths=host_lens)
             else:                                          # reverb: same rate, same lengths
@@ -623,7 +628,7 @@ class DataCollatorSpeechSeq2SeqWithPadding:
         setting of the HANDLE, so such a collator owns one of its own instead of toggling the
         shared one (which other callers may be using)."""
         from .feature_extractor import front_end
-        if self.output_dtype == torch.float32:
+        if self.output_dtype == torch.float32 and not self.private_handle:
             return front_end(n_mel, self.device)
         if self._fe16 is None or self._fe16.n_mel != n_mel:
             from .frontend import HipFrontEnd
@@ -656,7 +661,8 @@ class DataCollatorSpeechSeq2SeqWithPadding:
             for j, i in enumerate(gpu_items):
                 it = items[i]
                 ops, sr = it.get("aug_ops") or [], int(it.get("sample_rate", target))
-                if sr == int(it.get("target_rate", target)) and not any(is_host_op(op) for op in ops):
+                if sr == int(it.get("target_rate", target)) and not any(is_host_op(op) for op in ops) \
+                        and sum(1 for op in ops if op[0] == AUG_SPEED) <= 1:
                     simple.append(j)
                 else:
                     st = split_stages(ops, it["waveform"].shape[0], sr, int(it.get("target_rate", target)))
@@ -723,6 +729,118 @@ class DataCollatorSpeechSeq2SeqWithPaddingforEval(DataCollatorSpeechSeq2SeqWithP
 
     keep_prompt = True
     with_ids = True
+
+
+# ------------------------------------------------------------------ one batch ahead
+class PrefetchIterator:
+    """Iterates ``inner`` (a DataLoader iterator with ``num_workers=0``: dataset ``__getitems__`` + the GPU
+    collator) on a thread of the rank's MAIN process, one batch ahead of the consumer, so that the
+    host work of batch i+1 -- pread, packing, plan draws, tokenizer -- and its fused launch overlap the
+    training step of batch i.  What the reference gets from 8 forked workers (finetune.py:26,129),
+    without a fork (a forked worker cannot use the GPU).  The thread runs the collator on a stream of its
+    own; the consumer's current stream waits for the batch's event, and CUDA tensors of the batch are
+    recorded on it (allocator safety).  Order and contents are those of ``inner``; an exception of the
+    producer is re-raised by the ``next()`` that would have returned its batch."""
+
+    _END = object()
+
+    def __init__(self, inner, device=None, depth: int = 1):
+        import queue
+        import threading
+        self._inner = inner
+        self._q = queue.Queue(maxsize=max(1, int(depth)))
+        self._stop = threading.Event()
+        self._cuda = torch.cuda.is_available()
+        self._device = device
+        self._stream = None
+        self._done = False
+        self._thread = threading.Thread(target=self._produce, name="wfe-prefetch", daemon=True)
+        self._thread.start()
+
+    def _put(self, item) -> bool:
+        import queue
+        while not self._stop.is_set():
+            try:
+                self._q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def _produce(self):
+        try:
+            if self._cuda:
+                if self._device is not None:
+                    torch.cuda.set_device(self._device)
+                self._stream = torch.cuda.Stream()
+            while not self._stop.is_set():
+                ev = None
+                try:
+                    if self._cuda:
+                        with torch.cuda.stream(self._stream):
+                            batch = next(self._inner)
+                            ev = torch.cuda.Event()
+                            ev.record(self._stream)
+                    else:
+                        batch = next(self._inner)
+                except StopIteration:
+                    self._put((self._END, None, None))
+                    return
+                if not self._put((batch, ev, None)):
+                    return
+        except BaseException as e:  # noqa: BLE001 -- handed to the consumer
+            self._put((self._END, None, e))
+
+    def __iter__(self):
+        return self
+
+    def __len__(self):
+        return len(self._inner)
+
+    def __next__(self):
+        if self._done:
+            raise StopIteration
+        batch, ev, err = self._q.get()
+        if batch is self._END:
+            self._done = True
+            if err is not None:
+                raise err
+            raise StopIteration
+        if ev is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            for v in (batch.values() if isinstance(batch, dict) else ()):
+                if isinstance(v, torch.Tensor) and v.is_cuda:
+                    v.record_stream(cur)
+        return batch
+
+    def close(self):
+        self._stop.set()
+
+    def __del__(self):
+        self._stop.set()
+
+
+def install_prefetch() -> None:
+    """``DataLoader.__iter__`` returns a PrefetchIterator for loaders whose ``collate_fn`` is one of this
+    module's collators and that run in-process (``num_workers=0``).  WFE_PREFETCH=0 turns it off.
+    Such collators then use a front-end handle of their own (see ``private_handle``)."""
+    from torch.utils.data import DataLoader
+    if getattr(DataLoader.__iter__, "__wfe_prefetch__", False):
+        return
+    original = DataLoader.__iter__
+
+    def __iter__(self):
+        it = original(self)
+        coll = getattr(self, "collate_fn", None)
+        if (isinstance(coll, DataCollatorSpeechSeq2SeqWithPadding) and self.num_workers == 0
+                and os.environ.get("WFE_PREFETCH", "1") == "1"):
+            coll.private_handle = True
+            dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+            return PrefetchIterator(it, device=dev, depth=int(os.environ.get("WFE_PREFETCH_DEPTH", "1")))
+        return it
+    __iter__.__wfe_prefetch__ = True
+    DataLoader.__iter__ = __iter__
 
 
 # ------------------------------------------------------------------ text helpers

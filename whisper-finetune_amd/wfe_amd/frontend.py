@@ -28,7 +28,15 @@ class NoiseBank:
     """Noise clips resident on the device, back to back (the decoded contents of
     ``CustomDataset.noise_files``, utils/reader.py:75-78,323)."""
 
+    _serial = 0
+
+    @classmethod
+    def _next_serial(cls) -> int:
+        NoiseBank._serial += 1
+        return NoiseBank._serial
+
     def __init__(self, clips: Sequence[np.ndarray], device: torch.device):
+        self.serial = self._next_serial()       # identity of the CONTENTS (a freed bank's address may be reused)
         self.lengths = [int(len(c)) for c in clips]
         off = np.zeros(len(clips) + 1, dtype=np.int64)
         off[1:] = np.cumsum(self.lengths)
@@ -42,6 +50,7 @@ class NoiseBank:
     def from_tensors(cls, clips: Sequence[torch.Tensor], device: torch.device) -> "NoiseBank":
         """Clips that already live on the device (e.g. resampled there)."""
         self = cls.__new__(cls)
+        self.serial = cls._next_serial()
         self.lengths = [int(c.numel()) for c in clips]
         off = np.zeros(len(clips) + 1, dtype=np.int64)
         off[1:] = np.cumsum(self.lengths)
@@ -70,6 +79,7 @@ class HipFrontEnd:
         _lib.check(_lib.lib().wfe_create(C.byref(cfg), C.byref(h)), None)
         self._h = h
         self.out_dtype = torch.float32
+        self._bank_serial = None          # the NoiseBank whose mean squares the handle has cached
 
     _OUT_FORMATS = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}     # wfe_out_format
 
@@ -275,6 +285,17 @@ class HipFrontEnd:
                         raise ValueError(f"utterance {b}: noise start {start} outside clip {j} "
                                          f"({noise.lengths[j]} samples)")
 
+    def _use_bank(self, noise: Optional["NoiseBank"]) -> None:
+        """The library keeps the mean squares of the last noise bank it saw, keyed by its device
+        pointers (include/wfe.h wfe_noise_bank_changed).  torch's allocator hands a freed bank's
+        address to the next one, so the key here is the NoiseBank OBJECT: a different one -- or one
+        whose ``data`` was rewritten in place, after ``noise.serial`` was bumped -- drops the cache."""
+        if noise is None:
+            return
+        if noise.serial != self._bank_serial:
+            _lib.check(_lib.lib().wfe_noise_bank_changed(self._h), self._h)
+            self._bank_serial = noise.serial
+
     def _pack_ops(self, plans, noise=None):
         """Host op lists are validated and packed; a tuple from ``pack_plans`` is taken as it is
         (it was validated when it was packed IF a bank was given there)."""
@@ -292,6 +313,7 @@ class HipFrontEnd:
             raise ValueError("one op list per utterance")
         shape = (batch, self.n_mel, n_samples // HOP)
         out = self._out(out, shape)
+        self._use_bank(noise)
         tail = (_ptr(ops), _ptr(begin), total, _ptr(noise.data) if noise else None,
                 _ptr(noise.offsets) if noise else None, noise.n if noise else 0, _ptr(out), self._stream())
         if wav.dtype == torch.int16:
@@ -309,6 +331,7 @@ class HipFrontEnd:
         ops, begin, total = self._pack_ops(plans, noise)
         out = torch.empty((batch, n_samples), dtype=torch.float32, device=self.device)
         out_len = torch.empty((batch,), dtype=torch.int32, device=self.device)
+        self._use_bank(noise)
         _lib.check(_lib.lib().wfe_augment_waveform(
             self._h, _ptr(wav), _ptr(offsets), _ptr(lengths), stride, batch, int(n_samples), _ptr(ops), _ptr(begin),
             total, _ptr(noise.data) if noise else None, _ptr(noise.offsets) if noise else None,

@@ -19,6 +19,15 @@ What it does, in this process and before anything touches a GPU:
   * with ``WFE_INSTALL_EXTRACTOR=1``, ``WhisperProcessor.from_pretrained`` returns a
     processor whose feature extractor is the MI355X one (infer_tfs.py:27-37, evaluation.py:41-46).
 
+  * for scripts that use the front end: ``WFE_DEVICE_OUTPUT`` defaults to 1 and
+    ``Seq2SeqTrainingArguments`` / ``TrainingArguments`` default to ``dataloader_pin_memory=False`` (the
+    reference never sets it, finetune.py:111-133), so ``input_features`` stay on the GPU instead of going
+    GPU -> host -> pinned -> GPU; the DataLoader of the GPU collator is iterated one batch ahead on a thread
+    of the main process (``wfe_amd.data.install_prefetch``; WFE_PREFETCH=0 turns it off), which is what the
+    reference's 8 workers were for (finetune.py:26,129).  Keyword names that the installed transformers has
+    renamed since the reference was written (``evaluation_strategy`` -> ``eval_strategy``, the Trainer's
+    ``tokenizer=`` -> ``processing_class=``; finetune.py:120,149) are passed on under their new names.
+
 The script then runs in-process (``runpy.run_path``, ``__name__ == "__main__"``): no re-exec,
 so a torchrun-launched rank stays the process torchrun started.
 """
@@ -114,6 +123,43 @@ def _install_extractor_hook() -> None:
     WhisperProcessor.from_pretrained = classmethod(from_pretrained)
 
 
+def _install_training_defaults(note=sys.stderr) -> None:
+    """dataloader_pin_memory=False by default (CUDA tensors cannot be pinned) and the two keyword renames of
+    newer transformers releases.  Best effort: without transformers there is nothing to patch."""
+    try:
+        import inspect
+        import transformers
+    except Exception:  # noqa: BLE001
+        return
+    for cls_name in ("TrainingArguments", "Seq2SeqTrainingArguments"):
+        cls = getattr(transformers, cls_name, None)
+        if cls is None or getattr(cls.__init__, "__wfe_defaults__", False):
+            continue
+        original = cls.__init__
+        params = inspect.signature(original).parameters
+
+        def __init__(self, *args, __orig=original, __params=params, **kw):
+            kw.setdefault("dataloader_pin_memory", False)
+            if "evaluation_strategy" in kw and "evaluation_strategy" not in __params and "eval_strategy" in __params:
+                kw["eval_strategy"] = kw.pop("evaluation_strategy")
+            __orig(self, *args, **kw)
+        __init__.__wfe_defaults__ = True
+        cls.__init__ = __init__
+    for cls_name in ("Trainer", "Seq2SeqTrainer"):
+        cls = getattr(transformers, cls_name, None)
+        if cls is None or getattr(cls.__init__, "__wfe_defaults__", False):
+            continue
+        original = cls.__init__
+        params = inspect.signature(original).parameters
+
+        def __init__(self, *args, __orig=original, __params=params, **kw):
+            if "tokenizer" in kw and "tokenizer" not in __params and "processing_class" in __params:
+                kw["processing_class"] = kw.pop("tokenizer")
+            __orig(self, *args, **kw)
+        __init__.__wfe_defaults__ = True
+        cls.__init__ = __init__
+
+
 def main(argv=None) -> None:
     argv = list(sys.argv[1:] if argv is None else argv)
     if not argv or argv[0] in ("-h", "--help"):
@@ -125,6 +171,10 @@ def main(argv=None) -> None:
     args = argv[1:]
     if _uses_front_end(script):
         args = force_num_workers_zero(args)
+        os.environ.setdefault("WFE_DEVICE_OUTPUT", "1")      # features stay on the GPU ...
+        _install_training_defaults()                         # ... so the Trainer must not try to pin them
+        from .data import install_prefetch
+        install_prefetch()                                   # batch i + 1 is collated while step i runs
     install_redirect()
     if os.environ.get("WFE_INSTALL_EXTRACTOR", "0") == "1":
         _install_extractor_hook()
