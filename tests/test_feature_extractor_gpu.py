@@ -81,3 +81,26 @@ def test_other_feature_sizes():
         want = ol.logmel_f32([wav], n_mel=m)
         assert got.shape == want.shape == (1, m, 3000)
         assert np.abs(got - want).max() <= TOL, m
+
+
+def test_dither_matches_installed_reference_class():
+    """HF:146-147: dither * torch.randn on the padded batch, drawn from torch's global CPU generator -- a seeded
+    run sees the same noise with either class (do_normalize comes before the dither, the padding is dithered too)."""
+    transformers = pytest.importorskip("transformers")
+    from wfe_amd.feature_extractor import MI355XWhisperFeatureExtractor
+    ref = transformers.WhisperFeatureExtractor(feature_size=80, dither=1e-3)
+    fe = MI355XWhisperFeatureExtractor(feature_size=80, dither=1e-3)
+    rng = np.random.default_rng(11)
+    batch = [(0.2 * rng.standard_normal(n)).astype(np.float32) for n in (480000, 31234, 1600)]
+    for kw in ({}, {"do_normalize": True}, {"padding": "longest"}):
+        torch.manual_seed(99)
+        want = ref(batch, sampling_rate=16000, **kw)["input_features"]
+        after_ref = torch.rand(1).item()
+        torch.manual_seed(99)
+        got = fe(batch, sampling_rate=16000, **kw)["input_features"]
+        assert torch.rand(1).item() == after_ref, kw              # the same number of draws
+        assert got.shape == want.shape, kw
+        err = np.abs(got - want).max()
+        assert err <= TOL, (kw, err)
+        silent = fe(batch, sampling_rate=16000, **kw)["input_features"]
+        assert np.abs(silent - got).max() > 1e-3                  # the next draw is another noise

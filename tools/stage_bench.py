@@ -29,10 +29,12 @@ def timed(fn, steps=5, warmup=2):
 
 
 def main():
+    # python tools/stage_bench.py [rate ...]: only the resampler, from these rates (default: every case)
+    rates = tuple(int(a) for a in sys.argv[1:]) or (44100, 48000, 8000, 22050)
     B = 256
     fe = HipFrontEnd(n_mel=80, device=0)
     dev = fe.device
-    for sr in (44100, 48000, 8000, 22050):
+    for sr in rates:
         n = 30 * sr
         x = 0.1 * torch.randn((B, n), device=dev)
         lens = torch.full((B,), n, dtype=torch.int32, device=dev)
@@ -42,6 +44,8 @@ def main():
                           "ms": ms, "audio_hours_per_sec": B * 30 / 3600 / (ms / 1e3),
                           "in_plus_out_GBps": (B * n * 4 + B * 480000 * 4) / ms / 1e6}), flush=True)
         del x
+    if len(sys.argv) > 1:
+        return
     x = 0.1 * torch.randn((B, 480000), device=dev)
     lens = torch.full((B,), 480000, dtype=torch.int32, device=dev)
     for taps in (1600, 8000, 16000):

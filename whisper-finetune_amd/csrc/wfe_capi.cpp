@@ -709,6 +709,9 @@ int wfe_resample(wfe_handle h, const void* in, int32_t pcm_channels, const int64
         if (waste <= best) best = waste, t.nwaves = nw;
       }
       if (t.ptiles < 8) t.nwaves = t.ptiles;
+      // round 3: 12 waves = three per SIMD, tiles dealt to the SIMDs in turn and the last ptiles % 4 tiles split
+      // along the groups (resample_mfma_kernel); WFE_TUNE & 256 keeps round 2's count and assignment, for A/B
+      else if (!(h->tune & 256)) t.nwaves = 12;
       if (15LL * t.M * t.group + t.kspan + 1024 <= wfe::kRsMfmaSpanFloats && frag.size() <= (64u << 20)) {
         hipError_t e1 = hipMalloc(&t.d_frag, frag.size() * sizeof(float));
         hipError_t e2 = e1 == hipSuccess ? hipMalloc(&t.d_meta, meta.size() * sizeof(int)) : e1;

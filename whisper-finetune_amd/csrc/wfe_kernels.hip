@@ -35,6 +35,8 @@
 // float64 and rounded once.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "wfe_kernels.h"
 #include "wfe_layout.h"
 
@@ -61,6 +63,11 @@ constexpr int kStampRow = 16;   // 0..5 phase boundaries, 6 hardware id, 7 k-loo
 // 64 the k-loop's barriers, 128 its requests (twiddle and sample traffic), 256 its e / o adds.
 #ifndef WFE_ABLATE
 #define WFE_ABLATE 0
+#endif
+// The same for resample_mfma_kernel (make variant DEFS="-DWFE_FAST_BUILD -DWFE_RS_ABLATE=mask"; wrong results):
+// 1 the span's global loads, 2 the fragment loads, 4 the window reads from LDS, 8 the output stores, 16 the MFMAs.
+#ifndef WFE_RS_ABLATE
+#define WFE_RS_ABLATE 0
 #endif
 // Twiddle slots in LDS: kSlots k-steps of the table are parked at a time.  With 2 slots the workgroup
 // needs a barrier behind every k-step, with 4 (written 3 steps ahead instead of 2) behind every other one.
@@ -1413,7 +1420,12 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
   using lds_cptr = const __attribute__((address_space(3))) float*;
   lds_cptr fw_lo = (lds_cptr)(lds + rowbase + d_lo), fw_hi = (lds_cptr)(lds + rowbase + d_hi), fw_ev = (lds_cptr)(lds + rowbase + d_ev);
   lds_cptr bw_lo = (lds_cptr)(lds + rowbase - d_lo), bw_hi = (lds_cptr)(lds + rowbase - d_hi), bw_ev = (lds_cptr)(lds + rowbase - d_ev);
-  asm volatile("" : "+v"(fw_lo), "+v"(fw_hi), "+v"(fw_ev), "+v"(bw_lo), "+v"(bw_hi), "+v"(bw_ev));
+  // The image's pad word per hop (pad_q) makes a read's x / 160 term lane-dependent in the 8 steps whose four
+  // k-lanes straddle a multiple of 160 -- all of them BACKWARD reads of n = 65..96 (m = 400 - n around 320), and in
+  // every one of them it is the k-lanes with (kk & 1) == 0 that lie beyond: two more bases, one word further for
+  // those lanes, replace a compare / select / add per straddling read (48 vector instructions per tile).
+  lds_cptr bw_lo_x = bw_lo + ((kk & 1) ? 0 : 1), bw_ev_x = bw_ev + ((kk & 1) ? 0 : 1);
+  asm volatile("" : "+v"(fw_lo), "+v"(fw_hi), "+v"(fw_ev), "+v"(bw_lo), "+v"(bw_hi), "+v"(bw_ev), "+v"(bw_lo_x), "+v"(bw_ev_x));
   // sample n = dft_n_of(c, step, kk) of this lane's frame, or its mirror 400 - n
   auto sample_at = [&](int step, int c, int backward) {
     int nb, dl, c0;
@@ -1437,7 +1449,17 @@ __global__ __launch_bounds__(256, 2) void frontend_kernel(const FrontArgs a) {
     const int mm = kNfft - nn;
     // pad_q(160 j + x) = 161 j + x + x / 160; the x / 160 term is a compile-time
     // constant except in the few steps whose 4 k-lanes straddle 160 or 320
-    if (backward) return bw[kNfft - nb - c0 + 1 + (mm >= 2 * kHop ? 1 : 0)];
+    if (backward) {
+      // m >= 320 for all four k-lanes, for none, or (n = nb + c0 + {0, 2 | 4, 16, 18 | 20} around 80) for kk & 1 == 0 only
+      const int m_hi = kNfft - nb - c0, m_lo = m_hi - (c ? 18 : 20);          // m of k-lane 0 and of k-lane 3
+      if (m_hi >= 2 * kHop && m_lo < 2 * kHop) {
+        const int m_mid = m_hi - (c ? 2 : 4), m_next = m_hi - 16;              // k-lanes 2 (kk = 2) and 1
+        if (m_mid >= 2 * kHop && m_next < 2 * kHop && !(c && step == kSteps - 1))
+          return (c ? bw_lo_x : bw_ev_x)[kNfft - nb - c0 + 1];
+        return bw[kNfft - nb - c0 + 1 + (mm >= 2 * kHop ? 1 : 0)];
+      }
+      return bw[kNfft - nb - c0 + 1 + (m_hi >= 2 * kHop ? 1 : 0)];
+    }
     return fw[nb + c0 + (nn >= kHop ? 1 : 0)];
   };
   auto sample_request = [&](int step, int c, int backward) {
@@ -2012,22 +2034,21 @@ __global__ __launch_bounds__(256) void resolve_partial_kernel(const FrontArgs a,
     } else {
       if ((int)threadIdx.x < 4 * lo4 - lo) take(src.w[lo + threadIdx.x]);            // ragged head (< 4 samples)
       if ((int)threadIdx.x < hi - 4 * hi4) take(src.w[4 * hi4 + threadIdx.x]);       // ragged tail
-      int i = lo4 + (int)threadIdx.x;
-      for (; i + 768 < hi4; i += 1024) {
-        const f32x4 v0 = w4[i], v1 = w4[i + 256], v2 = w4[i + 512], v3 = w4[i + 768];
+      // Rows of 256 float4 in batches of kRows, every load of a batch in flight before the first sum: a part of a
+      // 30 s utterance is 29.3 rows per thread, i.e. two batches -- two memory round trips per workgroup where
+      // four-row batches plus a row-by-row tail made eleven (0.108 -> 0.0xx ms per 256 x 30 s).  A row beyond the
+      // part loads the part's last float4 and contributes nothing; the order of the sums is the row order, as before.
+      constexpr int kRows = 16;
+      for (int i0 = lo4 + (int)threadIdx.x; i0 - (int)threadIdx.x < hi4; i0 += 256 * kRows) {
+        f32x4 v[kRows];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) take(v0[e]);
+        for (int r = 0; r < kRows; ++r) v[r] = w4[min(i0 + 256 * r, hi4 - 1)];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) take(v1[e]);
+        for (int r = 0; r < kRows; ++r)
+          if (i0 + 256 * r < hi4) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) take(v2[e]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) take(v3[e]);
-      }
-      for (; i < hi4; i += 256) {
-        const f32x4 v = w4[i];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) take(v[e]);
+            for (int e = 0; e < 4; ++e) take(v[r][e]);
+          }
       }
     }
   } else if (k0 < 0) {
@@ -2476,11 +2497,182 @@ __global__ __launch_bounds__(256) void resample_decimate_kernel(const ResampleAr
 // 8 floats apart and meet in 4 or fewer LDS banks, so the span is stored with 4 extra floats per M (span index i
 // at i + 4 (i / M): window stride M + 4, 4 x odd); a k-step's 4 columns never cross a multiple of M, so its
 // extra offset is one wave-uniform number.
+// ---- the pieces of the matrix-core resampler, shared by its two kernels
+// Stage the input span [lo, lo + span) of one utterance into LDS with the threads t = 0 .. nt - 1 of the caller.
+template <bool PAD, int U = 4>
+__device__ __forceinline__ void rs_stage_span(const ResampleArgs& a, const Source& src, int len_in, long long lo, int span,
+                                              int M, float* __restrict__ xs, int t, int nt) {
+  if (!a.pcm && lo >= 0) {
+    // float32 source: 16-byte buffer loads (4-byte aligned is enough; dwords behind the utterance read as 0), U in
+    // flight per thread -- a CU keeps a bounded NUMBER of loads in flight, so the load instruction is the unit of cost
+    const __amdgpu_buffer_rsrc_t rx = f32_rsrc(src.w, lo, (long long)len_in - lo);
+    const int nvec = (span + 3) >> 2;
+    for (int v0 = t; v0 < nvec; v0 += nt * U) {
+      f32x4 X[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#if WFE_RS_ABLATE & 1
+        X[u] = f32x4{(float)v0, 1.f, 2.f, 3.f};
+#else
+        X[u] = buf_f32x4(rx, (v0 + nt * u) * 16);
+#endif
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (v0 + nt * u < nvec) {
+          const int v = v0 + nt * u;
+          reinterpret_cast<f32x4*>(xs)[PAD ? v + (4 * v) / M : v] = X[u];     // (M % 4 == 0: a quad stays inside one M)
+        }
+    }
+  } else {
+    for (int i0 = t; i0 < span; i0 += nt * 8) {        // 8 loads in flight per thread, branch-free (Source::gather)
+      int idx[8];
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const long long k = lo + i0 + nt * u;
+        idx[u] = (i0 + nt * u < span && k >= 0 && k < len_in) ? (int)k : -1;
+      }
+      src.gather<8>(idx, len_in, v);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (i0 + nt * u < span) {
+          const int i = i0 + nt * u;
+          xs[PAD ? i + 4 * (i / M) : i] = v[u];
+        }
+    }
+  }
+}
+
+// Column n of tile gt is group gt * 16 + n -- or, for odd M, tiles 2 t and 2 t + 1 take the even and the odd
+// groups of a run of 32: the 16 lanes of one k then read 2 M floats apart, an even stride with M odd, so with
+// the neighbouring k they cover 32 distinct LDS banks (M apart, the odd stride, half of them collide).
+template <int GT>
+__device__ __forceinline__ int rs_group_of(int gt, int lane, int M) {
+  const bool interleave = GT >= 2 && (M & 1);
+  return interleave ? (gt & 1) + 2 * ((lane & 15) + 16 * (gt >> 1)) : gt * 16 + (lane & 15);
+}
+
+// One unit of work: phase tile pt x the group tiles [G0, G0 + GN) of the span xs; store(group, phase p, v)
+// receives the lane's results for the phases p .. p + 3 of that group.
+template <int GT, bool PAD, int G0, int GN, class Store>
+__device__ __forceinline__ void rs_unit(const ResampleArgs& a, const float* __restrict__ xs, int pt, int lane, Store store) {
+  constexpr int P = PAD ? 4 : 0;
+  const int M = a.M;
+  const int kb_lo = __builtin_amdgcn_readfirstlane(a.frag_meta[3 * pt]);
+  const int nq = __builtin_amdgcn_readfirstlane(a.frag_meta[3 * pt + 1]);       // quads of k-steps
+  const int foff = __builtin_amdgcn_readfirstlane(a.frag_meta[3 * pt + 2]);     // in 64-lane float4 fragments
+  const float* xb[GT];
+#pragma unroll
+  for (int gt = G0; gt < G0 + GN; ++gt)
+    xb[gt] = xs + rs_group_of<GT>(gt, lane, M) * (M + P) + (lane >> 4) + (PAD ? 0 : 4 * kb_lo);
+  f32x4 acc[GT];
+#pragma unroll
+  for (int gt = G0; gt < G0 + GN; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // Fragments through a buffer resource (quad offset in an SGPR, one lane-offset VGPR), two register sets in
+  // rotation with the loads pinned TWO quads ahead of their use (round 2's single-quad "prefetch" compiled to a
+  // load and a full wait per quad).
+  const __amdgpu_buffer_rsrc_t fr =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.frag), 0, 0x7ffffff0, 0x00020000);
+  const int flane = lane * 16;
+  auto ldA = [&](int q) {                              // quad q of this tile (clamped: a repeat is never used)
+    const int qq = q < nq ? q : nq - 1;
+#if WFE_RS_ABLATE & 2
+    return f32x4{(float)qq, 1.f, (float)flane, 3.f};
+#else
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(fr, flane, (foff + qq) * 1024, 0));
+#endif
+  };
+  if (!PAD) {
+    // the quad loop unrolled by four: every window read is lane base + immediate, the bases move once per 16 GN MFMAs
+    auto quad = [&](const f32x4& A, int base) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int gt = G0; gt < G0 + GN; ++gt) {
+#if WFE_RS_ABLATE & 4
+          const float bv = A[(i + 1) & 3];
+#else
+          const float bv = xb[gt][base + 4 * i];
+#endif
+#if WFE_RS_ABLATE & 16
+          acc[gt][i] += A[i] * bv;
+#else
+          acc[gt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i], bv, acc[gt], 0, 0, 0);
+#endif
+        }
+    };
+    f32x4 X0 = ldA(0), X1 = ldA(1), Y0, Y1;
+    int q = 0;
+    for (; q + 4 <= nq; q += 4) {
+      Y0 = ldA(q + 2), Y1 = ldA(q + 3);
+      __builtin_amdgcn_sched_barrier(0);
+      quad(X0, 0);
+      quad(X1, 16);
+      X0 = ldA(q + 4), X1 = ldA(q + 5);
+      __builtin_amdgcn_sched_barrier(0);
+      quad(Y0, 32);
+      quad(Y1, 48);
+#pragma unroll
+      for (int gt = G0; gt < G0 + GN; ++gt) xb[gt] += 64;
+    }
+    if (q + 2 < nq) Y0 = ldA(q + 2);
+    if (q < nq) quad(X0, 0);
+    if (q + 1 < nq) quad(X1, 16);
+    if (q + 2 < nq) quad(Y0, 32);
+  } else {
+    // PAD: the k-step's LDS offset is a wave-uniform running number (column + 4 per M crossed)
+    int col = 4 * kb_lo, rem = col % M, cpad = col + P * (col / M);
+    f32x4 A = ldA(0);
+    for (int q = 0; q < nq; ++q) {
+      const f32x4 An = ldA(q + 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int gt = G0; gt < G0 + GN; ++gt)
+          acc[gt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i], xb[gt][cpad], acc[gt], 0, 0, 0);
+        rem += 4;
+        cpad += 4;
+        if (rem >= M) rem -= M, cpad += P;
+      }
+      A = An;
+    }
+  }
+#pragma unroll
+  for (int gt = G0; gt < G0 + GN; ++gt) store(rs_group_of<GT>(gt, lane, M), 16 * pt + 4 * (lane >> 4), acc[gt]);
+}
+
+// The units of wave `wave` of `nwaves`.  Round 2 gave wave w the tiles w, w + nwaves, ... whole; with 10 tiles on
+// 10 waves -- waves are dealt to the SIMDs round-robin, wave w runs on SIMD w & 3 -- the SIMDs carry 3 : 3 : 2 : 2
+// tiles.  Balanced (nwaves a multiple of 4): the first W = ptiles - ptiles % 4 tiles go WHOLE to the SIMDs in turn
+// (tile t to SIMD t & 3, there to that SIMD's waves in rotation); the remaining tiles are split along the group
+// tiles into GT units each and dealt on in the same rotation: L = 160 on 12 waves is 2 whole tiles + 1 half tile
+// per SIMD.  (A split tile's fragments are loaded once per unit.)
+template <int GT, class F>
+__device__ __forceinline__ void rs_deal_units(const ResampleArgs& a, int wave, int nwaves, F f) {
+  using std::integral_constant;
+  if ((a.tune & 256) || a.ptiles < 8 || (nwaves & 3)) {
+    for (int pt = wave; pt < a.ptiles; pt += nwaves) f(pt, integral_constant<int, 0>{}, integral_constant<int, GT>{});
+    return;
+  }
+  const int simd = wave & 3, slot = wave >> 2, c = nwaves >> 2;
+  const int W = a.ptiles & ~3;
+  for (int t = simd + 4 * slot; t < W; t += 4 * c) f(t, integral_constant<int, 0>{}, integral_constant<int, GT>{});
+  const int units = (a.ptiles - W) * GT;
+  for (int k = 0; simd + 4 * k < units; ++k) {
+    if ((W / 4 + k) % c != slot) continue;
+    const int v = simd + 4 * k, pt = W + v / GT, g = v % GT;
+    if (GT == 1 || g == 0) f(pt, integral_constant<int, 0>{}, integral_constant<int, 1>{});
+    else if (g == 1) f(pt, integral_constant<int, (GT > 1 ? 1 : 0)>{}, integral_constant<int, 1>{});
+    else if (g == 2) f(pt, integral_constant<int, (GT > 2 ? 2 : 0)>{}, integral_constant<int, 1>{});
+    else f(pt, integral_constant<int, (GT > 3 ? 3 : 0)>{}, integral_constant<int, 1>{});
+  }
+}
+
 template <int GT, bool PAD>
 __global__ __launch_bounds__(1024) void resample_mfma_kernel(const ResampleArgs a) {
   extern __shared__ __attribute__((aligned(16))) float xs_dyn[];
   float* xs = xs_dyn;
-  constexpr int G = 16 * GT, P = PAD ? 4 : 0;
+  constexpr int G = 16 * GT;
   const int tid = threadIdx.x, b = blockIdx.y, L = a.L, M = a.M;
   const int nthreads = blockDim.x, lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
   const long long g0 = (long long)blockIdx.x * G;
@@ -2505,87 +2697,37 @@ __global__ __launch_bounds__(1024) void resample_mfma_kernel(const ResampleArgs 
   src.ch = a.channels;
   const long long lo = g0 * M - a.k0;                  // span position i is input lo + i
   const int span = (G - 1) * M + a.kspan;              // (host: fits the dynamic LDS of the launch, rounded up to 4)
-  if (!a.pcm && lo >= 0) {
-    // float32 source: 16-byte buffer loads (4-byte aligned is enough; dwords behind the utterance read as 0), 4 in
-    // flight per thread -- a CU keeps a bounded NUMBER of loads in flight, so the load instruction is the unit of cost
-    const __amdgpu_buffer_rsrc_t rx = f32_rsrc(src.w, lo, (long long)len_in - lo);
-    const int nvec = (span + 3) >> 2;
-    for (int v0 = tid; v0 < nvec; v0 += nthreads * 4) {
-      f32x4 X[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) X[u] = buf_f32x4(rx, (v0 + nthreads * u) * 16);
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (v0 + nthreads * u < nvec) {
-          const int v = v0 + nthreads * u;
-          reinterpret_cast<f32x4*>(xs)[PAD ? v + (4 * v) / M : v] = X[u];     // (M % 4 == 0: a quad stays inside one M)
-        }
-    }
-  } else {
-    for (int i0 = tid; i0 < span; i0 += nthreads * 8) {  // 8 loads in flight per thread, branch-free (Source::gather)
-      int idx[8];
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const long long k = lo + i0 + nthreads * u;
-        idx[u] = (i0 + nthreads * u < span && k >= 0 && k < len_in) ? (int)k : -1;
-      }
-      src.gather<8>(idx, len_in, v);
-#pragma unroll
-      for (int u = 0; u < 8; ++u)
-        if (i0 + nthreads * u < span) {
-          const int i = i0 + nthreads * u;
-          xs[PAD ? i + 4 * (i / M) : i] = v[u];
-        }
-    }
-  }
+  rs_stage_span<PAD>(a, src, len_in, lo, span, M, xs, tid, nthreads);
   __syncthreads();
-  const f32x4* __restrict__ frag = reinterpret_cast<const f32x4*>(a.frag);
-  // Column n of tile gt is group gt * 16 + n -- or, for odd M, tiles 2 t and 2 t + 1 take the even and the odd
-  // groups of a run of 32: the 16 lanes of one k then read 2 M floats apart, an even stride with M odd, so with
-  // the neighbouring k they cover 32 distinct LDS banks (M apart, the odd stride, half of them collide).
-  const bool interleave = GT >= 2 && (M & 1);
-  auto group_of = [&](int gt) {
-    return interleave ? (gt & 1) + 2 * ((lane & 15) + 16 * (gt >> 1)) : gt * 16 + (lane & 15);
-  };
-  for (int pt = wave; pt < a.ptiles; pt += nwaves) {
-    const int kb_lo = __builtin_amdgcn_readfirstlane(a.frag_meta[3 * pt]);
-    const int nq = __builtin_amdgcn_readfirstlane(a.frag_meta[3 * pt + 1]);       // quads of k-steps
-    const int foff = __builtin_amdgcn_readfirstlane(a.frag_meta[3 * pt + 2]);     // in 64-lane float4 fragments
-    const f32x4* __restrict__ fp = frag + (long long)foff * 64 + lane;
-    const float* xb[GT];
+  // a lane's four consecutive outputs as ONE 16-byte store where they are whole and aligned: the 4 k-lanes of a
+  // group then fill a 64-byte segment per instruction (four scattered 4-byte stores per lane made the L2 fetch
+  // every output line back before writing it: FETCH_SIZE 390 MB above the input, profiles/round3_stages.txt)
+  const bool vec_ok = (L & 3) == 0 && (a.out_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(o) & 15u) == 0;
+  auto store = [&](int group, int p, const f32x4& v) {
+    const long long n = (g0 + group) * L + p;
+#if WFE_RS_ABLATE & 8
+    if (p < L && n < a.out_stride && v[0] == 12345.678f) o[n] = 1.f;
+#else
+    if (vec_ok && p + 3 < L && n + 3 < a.out_stride) {
+      *reinterpret_cast<f32x4*>(o + n) = f32x4{n < n_out ? v[0] : 0.f, n + 1 < n_out ? v[1] : 0.f,
+                                                n + 2 < n_out ? v[2] : 0.f, n + 3 < n_out ? v[3] : 0.f};
+    } else {
 #pragma unroll
-    for (int gt = 0; gt < GT; ++gt) xb[gt] = xs + group_of(gt) * (M + P) + (lane >> 4) + (PAD ? 0 : 4 * kb_lo);
-    int col = 4 * kb_lo, rem = col % M, cpad = col + P * (col / M);   // PAD: column of the k-step, col mod M, its LDS offset
-    f32x4 acc[GT];
-#pragma unroll
-    for (int gt = 0; gt < GT; ++gt) acc[gt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 A = fp[0];
-    for (int q = 0; q < nq; ++q) {
-      const f32x4 An = fp[(q + 1 < nq ? q + 1 : q) * 64];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int gt = 0; gt < GT; ++gt)
-          acc[gt] = __builtin_amdgcn_mfma_f32_16x16x4f32(A[i], xb[gt][PAD ? cpad : 16 * q + 4 * i], acc[gt], 0, 0, 0);
-        if (PAD) {
-          rem += 4;
-          cpad += 4;
-          if (rem >= M) rem -= M, cpad += P;
-        }
-      }
-      A = An;
+      for (int i = 0; i < 4; ++i)
+        if (p + i < L && n + i < a.out_stride) o[n + i] = (n + i < n_out) ? v[i] : 0.f;
     }
-#pragma unroll
-    for (int gt = 0; gt < GT; ++gt)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int p = 16 * pt + 4 * (lane >> 4) + i;
-        const long long n = (g0 + group_of(gt)) * L + p;
-        if (p < L && n < a.out_stride) o[n] = (n < n_out) ? acc[gt][i] : 0.f;
-      }
-  }
+#endif
+  };
+  rs_deal_units<GT>(a, wave, nwaves, [&](int pt, auto g0c, auto gnc) {
+    rs_unit<GT, PAD, decltype(g0c)::value, decltype(gnc)::value>(a, xs, pt, lane, store);
+  });
 }
+
+// (Round 3 also built this product as a PERSISTENT, software-pipelined workgroup -- one per CU, two span buffers,
+// 12 compute waves multiplying block i while 4 loader waves staged block i + 1 and wrote block i - 1 out of an LDS
+// tile; identical bits, and slower: 44.1 -> 16 kHz 1.41 - 1.54 ms per 256 x 30 s against 1.27 for the kernel above.
+// With one workgroup per CU nothing hides a block's serial latencies -- its scalar loads, the first fragment's L2
+// round trip, the barrier behind the slowest wave -- that a second, independent workgroup hides for free.  Removed.)
 
 // ------------------------------------------------------------- reverberation
 // scipy.signal.fftconvolve(sample, rir, mode='same') restated as the direct sum

@@ -108,8 +108,6 @@ class MI355XWhisperFeatureExtractor(WhisperFeatureExtractor):
                 f"The model corresponding to this feature extractor: {self.__class__.__name__} was trained using a"
                 f" sampling rate of {self.sampling_rate}. Please make sure that the provided `raw_speech` input"
                 f" was sampled with {self.sampling_rate} and not {sampling_rate}.")
-        if getattr(self, "dither", 0.0) != 0.0:
-            raise NotImplementedError("dither != 0 draws torch.randn on the host in the reference; not supported")
         # HF:278-294 input normalisation: always a batch, float32, mono
         if isinstance(raw_speech, torch.Tensor):
             raw_speech = raw_speech.detach().cpu().numpy()
@@ -126,7 +124,26 @@ class MI355XWhisperFeatureExtractor(WhisperFeatureExtractor):
                                     padding, max_length)
         fe = front_end(self.feature_size, self._device if device in (None, "cpu") else device)
         flat, off, lens = pack_ragged([w[:k] for w, k in zip(waves, kept)], fe.device)
-        if do_normalize:                                                           # HF:310-316
+        dither = float(getattr(self, "dither", 0.0) or 0.0)
+        if dither != 0.0:
+            # HF:146-147: `waveform += dither * torch.randn(waveform.shape)` on the PADDED batch (the zero padding
+            # is dithered too), drawn from torch's global CPU generator.  The draw stays on the host -- the same
+            # generator, shape and order, so a seeded run sees the reference's noise -- the multiply and the add
+            # are the same two float32 roundings on the GPU, and the dithered batch goes through the kernels at
+            # full length (no reference caller sets dither: not a hot path, one extra H2D copy).
+            if do_normalize:                                                       # HF:310-316, before the dither
+                plans = [[(_lib.AUG_AFFINE, 0, 0, 0, 0.0)] for _ in waves]
+                dense, _ = fe.augment_waveform(flat, lens, plans, None, n_samples=target, offsets=off)
+            else:
+                host = np.zeros((len(waves), target), dtype=np.float32)
+                for i, (w, k) in enumerate(zip(waves, kept)):
+                    host[i, :k] = w[:k]
+                dense = torch.from_numpy(host).to(fe.device)
+            noise = torch.randn((len(waves), target), dtype=torch.float32)
+            dense.add_(noise.to(fe.device).mul_(dither))
+            full = torch.full((len(waves),), target, dtype=torch.int32, device=fe.device)
+            feats = fe.logmel(dense, full, n_samples=target)
+        elif do_normalize:                                                         # HF:310-316
             plans = [[(_lib.AUG_AFFINE, 0, 0, 0, 0.0)] for _ in waves]
             feats = fe.augment_logmel(flat, lens, plans, None, n_samples=target, offsets=off)
         else:
