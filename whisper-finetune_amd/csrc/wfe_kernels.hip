@@ -1983,6 +1983,13 @@ __device__ inline double noise_meansq(const FrontArgs& a, int j) {
 // rms_db (utils/reader.py:350-353) under NumPy-2 float32 scalar semantics
 __device__ inline float rms_db_f32(double meansq) { return mul_rn(10.0f, log10f((float)meansq)); }
 
+// (Round 3 also built the sums INTO kernel 1: the workgroups of utterance b summed utterance b + 16, a part each, the
+// last of them resolved and published that chain with device-scope stores, and every workgroup waited -- bounded,
+// with a sum-it-yourself way out -- for its own utterance's ready word.  Identical bits to this pass on a mixed batch
+// and in the give-up path; and no faster: kernel 1 grew by 0.093 ms per 256 x 30 s, what this pass costs (0.100),
+// because every workgroup's prologue gained three serial memory round trips -- its part's loads, the ticket, the
+// ready word and then the head, which must come as device-scope loads -- that its partner workgroup only half
+// hides.  A pass of its own at 4.5 TB/s is the cheaper way to read the waveform twice.  Removed.)
 // Statistics of the signal ENTERING the first NOISE / AFFINE op of every utterance
 // (the only one in the reference's configurations), kResolveParts workgroups per
 // utterance so that the pass runs at HBM rate: float64 partial sums of x and x*x
@@ -2952,6 +2959,9 @@ static hipError_t launch_k1(const FrontArgs& a, int batch, hipStream_t stream) {
 // masks), 0 = any other feature_size (run-time masks).
 hipError_t launch_frontend(const FrontArgs& a, int batch, int mode, bool aug, int bank, hipStream_t stream) {
 #ifdef WFE_FAST_BUILD          // experiment builds (minutes less to compile): the two plain log-mel kernels only
+#if WFE_FAST_BUILD + 0 == 2    // (-DWFE_FAST_BUILD=2: and the 80-mel augmented one with its helpers)
+  if (mode == 0 && aug && bank == 1) return launch_k1<5, false, true, 1>(a, batch, stream);
+#endif
   if (mode == 0 && !aug && bank == 1) return launch_k1<5, false, false, 1>(a, batch, stream);
   if (mode == 0 && !aug && bank == 2) return launch_k1<8, false, false, 2>(a, batch, stream);
   if (mode == 1 && !aug) return launch_k1<5, true, false, 0>(a, batch, stream);
@@ -2984,7 +2994,7 @@ hipError_t launch_noise_meansq(const float* noise, const long long* off, int n_n
 }
 
 hipError_t launch_resolve(const FrontArgs& a, int batch, double* partials, unsigned* tickets, hipStream_t stream) {
-#ifdef WFE_FAST_BUILD
+#if defined(WFE_FAST_BUILD) && WFE_FAST_BUILD + 0 != 2
   return hipErrorInvalidValue;
 #endif
   hipLaunchKernelGGL(resolve_partial_kernel, dim3(kResolveParts, batch), dim3(256), 0, stream, a, partials, tickets);
@@ -2993,7 +3003,7 @@ hipError_t launch_resolve(const FrontArgs& a, int batch, double* partials, unsig
 
 hipError_t launch_waveform(const FrontArgs& a, int batch, float* out, int* out_lengths, hipStream_t stream) {
   const int gx = (a.n_samples + kBlockFrames * kHop - 1) / (kBlockFrames * kHop);
-#ifdef WFE_FAST_BUILD
+#if defined(WFE_FAST_BUILD) && WFE_FAST_BUILD + 0 != 2
   return hipErrorInvalidValue;
 #endif
   hipLaunchKernelGGL(waveform_kernel, dim3(gx < 1 ? 1 : gx, batch), dim3(256), 0, stream, a, out, out_lengths);
