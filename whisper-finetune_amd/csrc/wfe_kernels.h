@@ -24,7 +24,7 @@ struct ChainHead {
   int n_ops, speed_at, len1, compiled;   // compiled: cops hold the chain (n_ops <= 16)
   double step;
   // The chain shape the reference's own configuration draws ([NOISE]? [SPEED]? [SHIFT]? [VOLUME]?), matched
-  // once per utterance: everything kernel 1's contiguous staging needs, in one uniform 80-byte load instead
+  // once per utterance: everything kernel 1's contiguous staging needs, in one uniform 72-byte load instead
   // of the op array copied through LDS behind a barrier (absent SHIFT / VOLUME are shift 0 / gain 1.0f).
   int shipped;                           // 1: the fields below describe the whole chain
   int noise_k;                           // index of the NOISE op or -1
