@@ -141,6 +141,14 @@ def loaded_gpu_runtime():
     return sorted(hits)
 
 
+def one_gpu_rehearsal() -> bool:
+    """WFE_BENCH_ONE_GPU=1: every rank of a multi-rank run uses GPU 0 and the ranks talk over gloo -- the
+    whole multi-rank path (launch, rendezvous, shards, barriers, reductions, rank 0's line) with the real
+    front end on a box that has ONE GPU (tests/test_bench_gpu.py).  RCCL does not put two ranks on one
+    device; the line such a run prints says so and is never a measurement."""
+    return os.environ.get("WFE_BENCH_ONE_GPU", "0") == "1"
+
+
 def self_launch(args, argv) -> int:
     """--gpus N > 1 without WORLD_SIZE: start the N ranks from a process that has loaded neither
     torch nor the HIP runtime (nothing between process start and the spawn can reach hipInit:
@@ -148,7 +156,7 @@ def self_launch(args, argv) -> int:
     rank 0's JSON line, exit non-zero if any rank fails.  Never retried, never re-exec'd."""
     import socket
     import subprocess
-    if not args.stub_transform:
+    if not args.stub_transform and not one_gpu_rehearsal():
         n_dev = visible_gpu_count()
         if n_dev is not None and n_dev < args.gpus:
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible")
@@ -469,7 +477,9 @@ def shard_workload(args, fe, device, rank, world, dist, clips=None, quiet=False)
         "dtype": DTYPE_NAME[args.out_dtype], "data": "stub" if args.stub_transform else "synthetic",
         "config": {"workload": f"whisper-large-v3 {n_mel}-mel front end, {n_clips} synthetic 30 s "
                                f"clips sharded contiguously over {world} GPU(s), batches of {args.batch}"
-                               + (" [STUB TRANSFORM: plumbing test, not a measurement]" if args.stub_transform else ""),
+                               + (" [STUB TRANSFORM: plumbing test, not a measurement]" if args.stub_transform else "")
+                               + (" [REHEARSAL: all ranks on GPU 0 over gloo, not a measurement]"
+                                  if world > 1 and one_gpu_rehearsal() and not args.stub_transform else ""),
                    "parallelism": f"dp{world} (utterances sharded, no data-path collective)"},
         "clips_per_sec": res["items"] / res["seconds"], "items": res["items"], "checksum": res["checksum"]}
     if quiet:
@@ -596,13 +606,19 @@ def main(argv=None) -> None:
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the front end has no CPU path (0 GPU(s) visible)")
+    rehearsal = dist and one_gpu_rehearsal()
+    if rehearsal:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU (only {torch.cuda.device_count()} GPU(s) visible)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if dist:
         import torch.distributed as td
-        td.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            td.init_process_group("gloo")
+        else:
+            td.init_process_group("nccl", device_id=device)
 
     from wfe_amd.frontend import HipFrontEnd
     fe = HipFrontEnd(n_mel=args.n_mel, device=local_rank)
@@ -642,7 +658,7 @@ def main(argv=None) -> None:
     elapsed, k1_ms, k2_ms, launches = timed_steps(fe, step, args.steps, args.warmup, args.prewarm_ms, barrier)
 
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else device)
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -669,7 +685,8 @@ def main(argv=None) -> None:
                                    + ("" if args.out_dtype == "float32" else f"; output rounded to {args.out_dtype}"),
                        "batch_per_gpu": args.batch, "n_mel": args.n_mel, "clip_seconds": 30,
                        "prewarm_ms": args.prewarm_ms,
-                       "parallelism": f"dp{world} (utterances sharded, no data-path collective)"},
+                       "parallelism": f"dp{world} (utterances sharded, no data-path collective)"
+                                      + (" [REHEARSAL: all ranks on GPU 0 over gloo, not a measurement]" if rehearsal else "")},
             "clips_per_sec": clips / elapsed,
             "roofline": roofline_block(args.n_mel, args.batch, lens, k1_ms, k2_ms, launches, args.augment, args.lengths,
                                        not args.pcm16 and args.out_dtype == "float32"),
