@@ -99,7 +99,10 @@ def test_resample_argument_errors(fe):
 
 @pytest.mark.parametrize("orig,target", [(44100, 16000), (48000, 16000), (8000, 16000), (22050, 16000),
                                          (16000, 44100), (24000, 16000), (32000, 16000), (96000, 16000), (64000, 16000),
-                                         (12000, 16000), (16000, 8000), (16000, 32000), (16000, 24000)])
+                                         (12000, 16000), (16000, 8000), (16000, 32000), (16000, 24000),
+                                         # 25 and 15 tiles of 16 phases: one / three tiles left over by the four SIMDs
+                                         # (round 3: those are split along the groups), odd and even M
+                                         (17640, 16000), (4900, 24000), (11025, 16000)])
 def test_round2_kernels_match_round1_kernel(monkeypatch, orig, target):
     """Round 2's resamplers -- resample_mfma_kernel (the default: the banded filter matrix on the matrix cores) and,
     with WFE_TUNE=16, resample_decimate_kernel (few phases, sliding window) / resample_phase_kernel (a thread's
