@@ -197,3 +197,50 @@ def test_collator_output_dtype(tmp_path):
     assert again.dtype == torch.float32 and torch.equal(again, want)
     with pytest.raises(ValueError):
         wd.DataCollatorSpeechSeq2SeqWithPadding(processor=proc, output_dtype="int8")
+
+
+def test_prefetch_iterator_with_the_gpu_collator(tmp_path, monkeypatch):
+    """The one-batch-ahead iterator the launcher installs (wfe_amd.data.install_prefetch): the collator runs on a
+    thread of this process, on a stream and a front-end handle of its own, batch i + 1 is launched while batch i
+    is consumed.  Same draws in the same order, so the batches must be the bits of the plain in-line iteration --
+    with features left on the GPU (WFE_DEVICE_OUTPUT=1, the launcher's default) and read on ANOTHER stream than
+    the one they were produced on."""
+    from wfe_amd import data as wd
+    rng = np.random.default_rng(17)
+    recs = []
+    for i in range(23):
+        p = tmp_path / f"p{i}.wav"
+        _write_wav(p, 0.1 * rng.standard_normal(int((0.6 + 0.37 * i) * 16000)))
+        recs.append({"audio": {"path": str(p)}, "sentence": f"utt {i}", "duration": 0.6 + 0.37 * i})
+    mf = tmp_path / "list.json"
+    mf.write_text("\n".join(json.dumps(r) for r in recs))
+    cfgp = tmp_path / "aug.json"
+    cfgp.write_text(json.dumps([
+        {"type": "speed", "params": {"min_speed_rate": 0.9, "max_speed_rate": 1.1, "num_rates": 3}, "prob": 0.8},
+        {"type": "shift", "params": {"min_shift_ms": -5, "max_shift_ms": 5}, "prob": 0.8},
+        {"type": "volume", "params": {"min_gain_dBFS": -15, "max_gain_dBFS": 15}, "prob": 0.8}]))
+    monkeypatch.setenv("WFE_DEVICE_OUTPUT", "1")
+    proc = stubs.StubProcessor(n_mel=80)
+
+    def batches(prefetch):
+        ds = wd.CustomDataset(str(mf), proc, augment_config_path=str(cfgp))
+        coll = wd.DataCollatorSpeechSeq2SeqWithPadding(processor=proc, private_handle=prefetch)
+        it = iter(torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False, num_workers=0, collate_fn=coll))
+        if prefetch:
+            it = wd.PrefetchIterator(it, device=0)
+        random.seed(99)
+        out = []
+        side = torch.cuda.Stream()
+        for b in it:
+            assert b["input_features"].is_cuda
+            with torch.cuda.stream(side):                    # a consumer on a stream of its own
+                side.wait_stream(torch.cuda.current_stream())
+                out.append((b["input_features"].float().clone(), b["labels"].clone()))
+        torch.cuda.synchronize()
+        return out
+
+    plain = batches(False)
+    ahead = batches(True)
+    assert len(plain) == len(ahead) == 6
+    for (fa, la), (fb, lb) in zip(plain, ahead):
+        assert torch.equal(fa, fb) and torch.equal(la.cpu(), lb.cpu())
