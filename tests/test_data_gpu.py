@@ -225,10 +225,10 @@ def test_prefetch_iterator_with_the_gpu_collator(tmp_path, monkeypatch):
     def batches(prefetch):
         ds = wd.CustomDataset(str(mf), proc, augment_config_path=str(cfgp))
         coll = wd.DataCollatorSpeechSeq2SeqWithPadding(processor=proc, private_handle=prefetch)
+        random.seed(99)                                      # (before the producer thread starts drawing)
         it = iter(torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False, num_workers=0, collate_fn=coll))
         if prefetch:
             it = wd.PrefetchIterator(it, device=0)
-        random.seed(99)
         out = []
         side = torch.cuda.Stream()
         for b in it:
