@@ -147,7 +147,8 @@ int wfe_augment_logmel(wfe_handle h, const float* wav, const int64_t* offsets, c
  * utils/reader.py:329 -- is computed on the first augmented call that sees the bank and kept while
  * later calls pass the same `noise` / `noise_offsets` pointers and `n_noise`.  A caller that
  * rewrites a bank IN PLACE (same pointers, new samples) calls this before the next augmented
- * call; a new allocation needs nothing. */
+ * call; a new allocation needs nothing.  The call also drops the spectra wfe_reverb keeps of
+ * its impulse-response bank (same rule, same remedy). */
 int wfe_noise_bank_changed(wfe_handle h);
 
 /* The same two calls on 16-bit PCM as it lies in a WAV file, replacing the
@@ -186,8 +187,17 @@ int wfe_resample(wfe_handle h, const void* in, int32_t pcm_channels, const int64
                  float* out, int64_t out_stride, const int32_t* out_lengths, void* stream);
 
 /* CustomDataset.add_reverb (utils/reader.py:342-348) for a batch:
- * scipy.signal.fftconvolve(sample, rir, mode='same') as a direct float32 sum, then
- * y * (max|sample| / max|y|).  Utterances with rir_index[b] < 0 are copied through.
+ * scipy.signal.fftconvolve(sample, rir, mode='same'), then y * (max|sample| / max|y|).
+ * Utterances with rir_index[b] < 0 are copied through.  The convolution is a direct float32
+ * sum while the bank's longest response is shorter than 512 taps, and a partitioned
+ * overlap-save FFT convolution (4096-point float32 transforms) from there on; both agree with
+ * the float64 convolution to 3e-6 max|y| sqrt(taps / 64).  The FFT form reads the bank's
+ * lengths back ONCE per bank (a stream synchronisation on the first call that sees it) and
+ * keeps the responses' spectra while later calls pass the same `rir` / `rir_offsets`
+ * pointers and `n_rir`; a caller that rewrites a bank IN PLACE calls wfe_noise_bank_changed
+ * (which forgets this cache too).  Workspace of the FFT form, kept by the handle:
+ * about 0.26 MB per second of audio at 16 kHz and utterance of the batch from four partitions
+ * of 2048 taps on (2 GB for 256 x 30 s with a 1 s response), less for shorter responses.
  *   wav / offsets / lengths / row_stride   as wfe_logmel (float32 only)
  *   rir, rir_offsets   device float32 impulse responses back to back and their
  *                      int64[n_rir + 1] prefix offsets (already at the utterances' rate:

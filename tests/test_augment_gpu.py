@@ -493,12 +493,12 @@ def test_reverb_matches_scipy_fftconvolve(fe):
 @pytest.mark.parametrize("taps", [1, 7, 8, 9, 511, 512, 513, 1601])
 def test_reverb_window_kernel_matches_round1_kernel(monkeypatch, taps):
     """reverb_window_kernel (8 consecutive outputs per thread, the input window in registers) accumulates every
-    output's taps in the same order as reverb_kernel (WFE_TUNE=4 keeps that one): identical bits, for impulse
+    output's taps in the same order as reverb_kernel (WFE_TUNE & 4 keeps that one): identical bits, for impulse
     responses around the block (8) and chunk (512) sizes, odd and even, ragged utterances, one copied through."""
     from wfe_amd.frontend import HipFrontEnd, NoiseBank
-    monkeypatch.delenv("WFE_TUNE", raising=False)
+    monkeypatch.setenv("WFE_TUNE", "8192")             # (the direct sum for every length: banks from 512 taps on take the FFT form)
     fe_new = HipFrontEnd(n_mel=80, device=0)
-    monkeypatch.setenv("WFE_TUNE", "4")
+    monkeypatch.setenv("WFE_TUNE", str(8192 + 4))
     fe_old = HipFrontEnd(n_mel=80, device=0)
     n = 50000
     g = torch.Generator(device="cuda").manual_seed(taps)
@@ -511,3 +511,102 @@ def test_reverb_window_kernel_matches_round1_kernel(monkeypatch, taps):
     b = fe_old.reverb(x, lens, NoiseBank(clips, fe_old.device), idx, host_lengths=host)
     torch.cuda.synchronize()
     assert torch.equal(a, b)
+
+
+def _reverb_float64(x, h):
+    """add_reverb (reader.py:342-348) in float64: fftconvolve(mode='same'), then the peak normalisation."""
+    from scipy.signal import fftconvolve
+    y = fftconvolve(x.astype(np.float64), h.astype(np.float64), mode="same")
+    return y * (np.abs(x).max() / np.abs(y).max())
+
+
+@pytest.mark.parametrize("taps,tune", [(512, 0), (2048, 0), (2049, 0), (4096, 0), (4097, 0), (6144, 0), (6145, 0), (6145, 16384),
+                                       (16000, 0), (16000, 16384), (16385, 0), (40000, 0)])
+def test_reverb_fft_forms_match_float64_convolution(monkeypatch, taps, tune):
+    """Impulse-response banks whose longest response has 512 taps or more take the partitioned overlap-save FFT form
+    (wfe_reverb_fft.hip): one kernel up to three partitions of 2048 taps, three kernels beyond (WFE_TUNE & 16384: one
+    kernel for every length).  Against add_reverb in float64, with the bound of the direct sum's test
+    (3e-6 max|y| sqrt(taps / 64); measured ~1e-7, below the direct sum's own error), on ragged utterances -- empty,
+    shorter than a block, shorter than the response, block-aligned -- with responses of different partition counts
+    in one bank, one utterance copied through; rows zero behind their lengths; and close to the direct-sum kernel."""
+    from wfe_amd.frontend import HipFrontEnd, NoiseBank
+    monkeypatch.setenv("WFE_TUNE", str(tune))
+    fe_fft = HipFrontEnd(n_mel=80, device=0)
+    monkeypatch.setenv("WFE_TUNE", "8192")
+    fe_dir = HipFrontEnd(n_mel=80, device=0)
+    n = 70000
+    g = torch.Generator(device="cuda").manual_seed(taps)
+    x = 0.1 * torch.randn((10, n), generator=g, device="cuda")
+    host = [n, n // 3, 5, 2049, 0, 4096, 2048, 1, 69999, 12288]
+    lens = torch.tensor(host, dtype=torch.int32, device="cuda")
+    clips = [_rir(taps, taps), _rir(taps + 1, max(taps - 1, 1)), _rir(3, 300), _rir(4, 1), _rir(5, taps // 2 + 1)]
+    idx = [0, 1, 0, 1, 0, -1, 2, 0, 4, 3]
+    a = fe_fft.reverb(x, lens, NoiseBank(clips, fe_fft.device), idx, host_lengths=host)
+    d = fe_dir.reverb(x, lens, NoiseBank(clips, fe_dir.device), idx, host_lengths=host)
+    torch.cuda.synchronize()
+    a, d, xh = a.cpu().numpy(), d.cpu().numpy(), x.cpu().numpy()
+    worst = 0.0
+    for b, (m, j) in enumerate(zip(host, idx)):
+        assert not a[b, m:].any(), b
+        if m == 0:
+            continue
+        if j < 0:
+            assert np.array_equal(a[b, :m], xh[b, :m])
+            continue
+        want = _reverb_float64(xh[b, :m], clips[j])
+        scale = np.abs(want).max() * max(1.0, np.sqrt(len(clips[j]) / 64))
+        err = np.abs(a[b, :m] - want).max() / scale
+        worst = max(worst, err)
+        assert err <= 3e-6, (b, m, len(clips[j]), err)
+        assert np.abs(a[b, :m] - d[b, :m]).max() / scale <= 3e-6, b
+    print(f"taps {taps} tune {tune}: worst error / (max|y| sqrt(taps/64)) = {worst:.2e}")
+
+
+def test_reverb_fft_beyond_the_products_lds_uses_one_kernel():
+    """The three-kernel form keeps 2 P8 + 8 KB of a response's spectra in LDS (P8 = partitions rounded up to 8): from
+    73 partitions on (149 505 taps, 9.3 s at 16 kHz) the one-kernel form runs instead, whatever the length."""
+    from wfe_amd.frontend import HipFrontEnd, NoiseBank
+    fe = HipFrontEnd(n_mel=80, device=0)
+    taps = 150000
+    x = 0.1 * torch.randn((2, 30000), generator=torch.Generator(device="cuda").manual_seed(7), device="cuda")
+    host = [30000, 9000]
+    lens = torch.tensor(host, dtype=torch.int32, device="cuda")
+    clips = [_rir(9, taps)]
+    a = fe.reverb(x, lens, NoiseBank(clips, fe.device), [0, 0], host_lengths=host).cpu().numpy()
+    xh = x.cpu().numpy()
+    for b, m in enumerate(host):
+        want = _reverb_float64(xh[b, :m], clips[0])
+        assert np.abs(a[b, :m] - want).max() <= 3e-6 * np.abs(want).max() * np.sqrt(taps / 64)
+        assert not a[b, m:].any()
+
+
+def test_reverb_spectra_cache_follows_the_bank():
+    """The handle keeps the spectra of the last impulse-response bank it saw, keyed by pointers and count.  A new bank
+    at a reused device address, a bank rewritten in place (serial bumped: wfe_noise_bank_changed) and a switch between
+    a short bank (direct sum) and a long one must all be seen."""
+    from wfe_amd.frontend import HipFrontEnd, NoiseBank
+    fe = HipFrontEnd(n_mel=80, device=0)
+    x = 0.1 * torch.randn((3, 20000), generator=torch.Generator(device="cuda").manual_seed(11), device="cuda")
+    host = [20000, 15000, 4097]
+    lens = torch.tensor(host, dtype=torch.int32, device="cuda")
+    xh = x.cpu().numpy()
+
+    def check(out, clips, idx):
+        out = out.cpu().numpy()
+        for b, m in enumerate(host):
+            want = _reverb_float64(xh[b, :m], clips[idx[b]])
+            assert np.abs(out[b, :m] - want).max() <= 3e-6 * np.abs(want).max() * max(1.0, np.sqrt(len(clips[idx[b]]) / 64)), b
+    one = [_rir(20, 5000), _rir(21, 3000)]
+    two = [_rir(22, 5000), _rir(23, 3000)]             # same sizes: the same addresses when the first bank is freed
+    idx = [0, 1, 0]
+    nb = NoiseBank(one, fe.device)
+    check(fe.reverb(x, lens, nb, idx, host_lengths=host), one, idx)
+    del nb
+    nb2 = NoiseBank(two, fe.device)
+    check(fe.reverb(x, lens, nb2, idx, host_lengths=host), two, idx)
+    nb2.data.copy_(torch.from_numpy(np.concatenate(one)).to(fe.device))
+    nb2.serial = NoiseBank._next_serial()
+    check(fe.reverb(x, lens, nb2, idx, host_lengths=host), one, idx)
+    short = [_rir(24, 100), _rir(25, 64)]
+    check(fe.reverb(x, lens, NoiseBank(short, fe.device), idx, host_lengths=host), short, idx)
+    check(fe.reverb(x, lens, nb2, idx, host_lengths=host), one, idx)

@@ -3,6 +3,7 @@
 // across the boundary.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -54,6 +55,15 @@ struct wfe_context {
   unsigned long long* d_stamps = nullptr;   // diagnostic builds only (wfe_debug_stamps)
   // augmented calls: the resolve pass (HBM-bound) of the second half of a batch runs on this stream under
   // kernel 1 (matrix-bound) of the first half; forked from and joined to the caller's stream with the two events
+  // reverberation by FFT (wfe_reverb_fft.hip): twiddle tables, and the spectra of the impulse-response bank last seen
+  float2* d_rv_tw = nullptr;
+  float2* d_rv_H = nullptr;
+  size_t rv_H_cap = 0;                      // float2 elements
+  const float* rv_rir_seen = nullptr;
+  const int64_t* rv_off_seen = nullptr;
+  int rv_n_seen = 0, rv_p_max = 0, rv_max_taps = 0;
+  float2* d_rv_ring = nullptr;              // the one-kernel form's ring, or the three-kernel form's Z then Y
+  size_t rv_ring_cap = 0;                   // float2 elements
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::vector<char> ev_cont;                // per event triple: 1 = second half of the same call (not a launch of its own)
@@ -423,6 +433,9 @@ int wfe_destroy(wfe_handle h) {
   }
   if (h->d_partials) (void)hipFree(h->d_partials);
   if (h->d_tickets) (void)hipFree(h->d_tickets);
+  if (h->d_rv_tw) (void)hipFree(h->d_rv_tw);
+  if (h->d_rv_H) (void)hipFree(h->d_rv_H);
+  if (h->d_rv_ring) (void)hipFree(h->d_rv_ring);
   if (h->d_peaks) (void)hipFree(h->d_peaks);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -462,6 +475,9 @@ int wfe_noise_bank_changed(wfe_handle h) {
   h->noise_seen = nullptr;
   h->noise_off_seen = nullptr;
   h->n_noise_seen = 0;
+  h->rv_rir_seen = nullptr;              // (and the impulse-response bank's cached spectra)
+  h->rv_off_seen = nullptr;
+  h->rv_n_seen = 0;
   return WFE_OK;
 }
 
@@ -606,6 +622,51 @@ int wfe_reverb(wfe_handle h, const float* wav, const int64_t* offsets, const int
   DeviceGuard guard(h->cfg.device);
   if (!guard.ok) return fail(h, WFE_ERR_HIP, "hipSetDevice(%d) failed", h->cfg.device);
   if (!h->d_peaks) HIP_TRY(h, hipMalloc(&h->d_peaks, sizeof(unsigned) * 2 * kMaxBatchPerLaunch));
+  // Long impulse responses: the FFT form (wfe_reverb_fft.hip).  The bank's lengths are read back ONCE per bank (same
+  // pointers and count; wfe_noise_bank_changed also forgets this one), its spectra are computed once and kept.
+  // (WFE_TUNE & 8192: the direct sum for every length, for A/B and the tests.)
+  bool use_fft = false;
+  if (n_rir > 0 && !(h->tune & 8192)) {
+    if (h->rv_rir_seen != rir || h->rv_off_seen != rir_offsets || h->rv_n_seen != n_rir) {
+      std::vector<int64_t> off((size_t)n_rir + 1);
+      HIP_TRY(h, hipMemcpyAsync(off.data(), rir_offsets, off.size() * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+      HIP_TRY(h, hipStreamSynchronize(stream));
+      int max_taps = 0;
+      for (int j = 0; j < n_rir; ++j) {
+        const int64_t t = off[j + 1] - off[j];
+        if (t < 0 || t >= (1LL << 30)) return fail(h, WFE_ERR_ARG, "impulse response %d: bad length", j);
+        if (t > max_taps) max_taps = (int)t;
+      }
+      h->rv_rir_seen = rir;
+      h->rv_off_seen = rir_offsets;
+      h->rv_n_seen = n_rir;
+      h->rv_max_taps = max_taps;
+      h->rv_p_max = (max_taps + wfe::kRvFftN / 2 - 1) / (wfe::kRvFftN / 2);
+      if (max_taps >= wfe::kRvFftMinTaps) {
+        if (!h->d_rv_tw) {
+          std::vector<float2> tw(128);
+          const double w = -2.0 * 3.14159265358979323846 / (double)wfe::kRvFftN;
+          for (int i = 0; i < 64; ++i) {
+            tw[i] = float2{(float)std::cos(w * 64.0 * i), (float)std::sin(w * 64.0 * i)};
+            tw[64 + i] = float2{(float)std::cos(w * i), (float)std::sin(w * i)};
+          }
+          HIP_TRY(h, hipMalloc(&h->d_rv_tw, tw.size() * sizeof(float2)));
+          HIP_TRY(h, hipMemcpy(h->d_rv_tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
+        }
+        const size_t need = (size_t)n_rir * h->rv_p_max * wfe::kRvFftN;
+        if (need > h->rv_H_cap) {
+          if (h->d_rv_H) HIP_TRY(h, hipFree(h->d_rv_H));
+          h->d_rv_H = nullptr;
+          h->rv_H_cap = 0;
+          HIP_TRY(h, hipMalloc(&h->d_rv_H, need * sizeof(float2)));
+          h->rv_H_cap = need;
+        }
+        HIP_TRY(h, wfe::launch_reverb_spectra(rir, reinterpret_cast<const long long*>(rir_offsets), n_rir, h->rv_p_max,
+                                              h->d_rv_tw, h->d_rv_H, stream));
+      }
+    }
+    use_fft = h->rv_max_taps >= wfe::kRvFftMinTaps;
+  }
   for (const Slice& s : slices(batch)) {
     wfe::ReverbArgs a;
     std::memset(&a, 0, sizeof a);
@@ -621,6 +682,45 @@ int wfe_reverb(wfe_handle h, const float* wav, const int64_t* offsets, const int
     a.peaks = h->d_peaks;
     a.tune = h->tune;
     HIP_TRY(h, hipMemsetAsync(h->d_peaks, 0, sizeof(unsigned) * 2 * kMaxBatchPerLaunch, stream));
+    if (use_fft) {
+      const int B = wfe::kRvFftN / 2, P = h->rv_p_max;
+      const long long blocks = (out_stride + B - 1) / B + 1;                  // blocks of the full convolution per utterance, at most
+      // three kernels from four partitions on (the products read every spectrum once instead of once per partition),
+      // while the products' LDS fits; (WFE_TUNE & 16384: the one-kernel form for every length)
+      const bool three = P >= 4 && !(h->tune & 16384) && wfe::reverb_mac_lds_bytes(P) <= wfe::kRvMacLdsMax;
+      int segments = 1, seg_blocks = 1;
+      const long long kh_cap = (blocks + 1) / 2, pairs_cap = kh_cap + P - 1;
+      size_t need;
+      if (three) {
+        need = (size_t)s.count * (size_t)(pairs_cap + kh_cap) * wfe::kRvFftN;
+      } else {
+        // cut into segments so that a launch has ~4 workgroups per CU (a segment starts P - 1 pairs early)
+        long long want = (1024 + s.count - 1) / s.count;
+        const long long most = blocks / (2LL * P + 2) > 0 ? blocks / (2LL * P + 2) : 1;
+        if (want > most) want = most;
+        if (want < 1) want = 1;
+        seg_blocks = (int)((blocks + want - 1) / want);
+        segments = (int)((blocks + seg_blocks - 1) / seg_blocks);
+        need = (size_t)s.count * segments * P * wfe::kRvFftN;
+      }
+      if (need > h->rv_ring_cap) {
+        if (h->d_rv_ring) HIP_TRY(h, hipFree(h->d_rv_ring));
+        h->d_rv_ring = nullptr;
+        h->rv_ring_cap = 0;
+        HIP_TRY(h, hipMalloc(&h->d_rv_ring, need * sizeof(float2)));
+        h->rv_ring_cap = need;
+      }
+      HIP_TRY(h, hipMemsetAsync(a.out, 0, (size_t)s.count * out_stride * sizeof(float), stream));   // rows are zero behind their lengths
+      if (three) {
+        float2* Z = h->d_rv_ring;
+        float2* Y = Z + (size_t)s.count * (size_t)pairs_cap * wfe::kRvFftN;
+        HIP_TRY(h, wfe::launch_reverb_fft3(a, s.count, h->d_rv_tw, h->d_rv_H, P, Z, (int)pairs_cap, Y, (int)kh_cap, stream));
+      } else {
+        HIP_TRY(h, wfe::launch_reverb_fft(a, s.count, h->d_rv_tw, h->d_rv_H, P, h->d_rv_ring, segments, seg_blocks, stream));
+      }
+      HIP_TRY(h, wfe::launch_reverb_scale(a, s.count, stream));
+      continue;
+    }
     HIP_TRY(h, wfe::launch_reverb(a, s.count, stream));
   }
   return WFE_OK;

@@ -127,5 +127,29 @@ struct ReverbArgs {
   int tune;                      // experiment switches (WFE_TUNE)
 };
 hipError_t launch_reverb(const ReverbArgs& a, int batch, hipStream_t stream);
+hipError_t launch_reverb_scale(const ReverbArgs& a, int batch, hipStream_t stream);   // (the second pass of launch_reverb alone)
+
+// ---- the same for long impulse responses: partitioned overlap-save FFT convolution (wfe_reverb_fft.hip)
+constexpr int kRvFftN = 4096;          // transform size; partitions and output blocks of N / 2
+#ifndef WFE_RV_FFT_MIN_TAPS
+#define WFE_RV_FFT_MIN_TAPS 512
+#endif
+constexpr int kRvFftMinTaps = WFE_RV_FFT_MIN_TAPS;   // banks whose longest response has at least this many taps take the FFT path
+// tw: 128 float2 = exp(-2 pi i 64 a / N), a < 64, then exp(-2 pi i b / N), b < 64 (built in float64 on the host)
+// H: (n_rir x p_max x N) spectra of the response partitions / N
+hipError_t launch_reverb_spectra(const float* rir, const long long* rir_off, int n_rir, int p_max, const float2* tw, float2* H,
+                                 hipStream_t stream);
+// One kernel (responses of one or two partitions).  ring: (batch x segments x p_max x N) float2 workspace; a.out rows
+// must be zero behind their lengths already
+hipError_t launch_reverb_fft(const ReverbArgs& a, int batch, const float2* tw, const float2* H, int p_max, float2* ring,
+                             int segments, int seg_blocks, hipStream_t stream);
+// Three kernels (forward transforms -> products by the owner of a bin -> inverse transforms), for longer responses.
+// blocks_cap = ceil(out_stride / (N / 2)) + 1, kh_cap = ceil(blocks_cap / 2), pairs_cap = kh_cap + p_max - 1;
+// Z: (batch x pairs_cap x N), Y: (batch x kh_cap x N) float2 workspaces.  The products' kernel needs
+// reverb_mac_lds_bytes(p_max) of LDS: at most kRvMacLdsMax.
+constexpr int kRvMacLdsMax = 152 * 1024;
+int reverb_mac_lds_bytes(int p_max);
+hipError_t launch_reverb_fft3(const ReverbArgs& a, int batch, const float2* tw, const float2* H, int p_max, float2* Z,
+                              int pairs_cap, float2* Y, int kh_cap, hipStream_t stream);
 
 }  // namespace wfe

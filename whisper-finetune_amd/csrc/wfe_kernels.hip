@@ -3018,6 +3018,10 @@ hipError_t launch_reverb(const ReverbArgs& a, int batch, hipStream_t stream) {
     hipLaunchKernelGGL(reverb_window_kernel, dim3((unsigned)(gx < 1 ? 1 : gx), batch), dim3(256), 0, stream, a);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
+  return launch_reverb_scale(a, batch, stream);
+}
+
+hipError_t launch_reverb_scale(const ReverbArgs& a, int batch, hipStream_t stream) {
   long long sx = (a.out_stride + 256 * 8 - 1) / (256 * 8);
   if (sx > 256) sx = 256;
   hipLaunchKernelGGL(reverb_scale_kernel, dim3((unsigned)(sx < 1 ? 1 : sx), batch), dim3(256), 0, stream, a);

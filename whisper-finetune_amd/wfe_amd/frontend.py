@@ -80,6 +80,7 @@ class HipFrontEnd:
         self._h = h
         self.out_dtype = torch.float32
         self._bank_serial = None          # the NoiseBank whose mean squares the handle has cached
+        self._rir_serial = None           # the impulse-response bank whose spectra it has cached (reverb)
 
     _OUT_FORMATS = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}     # wfe_out_format
 
@@ -230,6 +231,9 @@ class HipFrontEnd:
             out_stride = (max(max(host_lengths, default=1), 1) + 3) // 4 * 4
         out = torch.empty((batch, int(out_stride)), dtype=torch.float32, device=self.device)
         idx = torch.tensor([int(i) for i in rir_index], dtype=torch.int32).to(self.device)
+        if rirs.serial != self._rir_serial:           # (the library keeps the bank's spectra by pointer, as _use_bank)
+            _lib.check(_lib.lib().wfe_noise_bank_changed(self._h), self._h)
+            self._rir_serial = rirs.serial
         _lib.check(_lib.lib().wfe_reverb(self._h, _ptr(wav), _ptr(offsets), _ptr(lengths), stride, batch,
                                          _ptr(rirs.data), _ptr(rirs.offsets), rirs.n, _ptr(idx), _ptr(out),
                                          int(out_stride), self._stream()), self._h)
