@@ -685,9 +685,9 @@ int wfe_reverb(wfe_handle h, const float* wav, const int64_t* offsets, const int
     if (use_fft) {
       const int B = wfe::kRvFftN / 2, P = h->rv_p_max;
       const long long blocks = (out_stride + B - 1) / B + 1;                  // blocks of the full convolution per utterance, at most
-      // three kernels from four partitions on (the products read every spectrum once instead of once per partition),
+      // three kernels from three partitions on (the products read every spectrum once instead of once per partition),
       // while the products' LDS fits; (WFE_TUNE & 16384: the one-kernel form for every length)
-      const bool three = P >= 4 && !(h->tune & 16384) && wfe::reverb_mac_lds_bytes(P) <= wfe::kRvMacLdsMax;
+      const bool three = P >= 3 && !(h->tune & 16384) && wfe::reverb_mac_lds_bytes(P) <= wfe::kRvMacLdsMax;
       int segments = 1, seg_blocks = 1;
       const long long kh_cap = (blocks + 1) / 2, pairs_cap = kh_cap + P - 1;
       size_t need;

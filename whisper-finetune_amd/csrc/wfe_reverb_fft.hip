@@ -146,10 +146,12 @@ __device__ __forceinline__ Utt utterance(const ReverbArgs& a, int b, const c32* 
 }
 
 // the windows of blocks ka (real part) and kb (imaginary part; zero unless b_valid), and the peak of what was read
+// (R0 = 8: the first halves are the second halves of the pair before, which the caller still holds)
+template <int R0 = 0>
 __device__ __forceinline__ void load_windows(c32 (&v)[16], const Utt& u, int ka, int kb, bool b_valid, int tid, float& pk_x) {
   const long long sa = (long long)(ka - 1) * kB + tid, sb = (long long)(kb - 1) * kB + tid;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
+  for (int r = R0; r < 16; ++r) {
     const long long ia = sa + 256 * r, ib = sb + 256 * r;
     const float xa = (ia >= 0 && ia < u.len) ? u.x[ia] : 0.f;
     const float xb = (b_valid && ib >= 0 && ib < u.len) ? u.x[ib] : 0.f;
@@ -238,11 +240,19 @@ __global__ __launch_bounds__(256) void reverb_fft_kernel(const ReverbArgs a, con
   c32* __restrict__ my_ring = ring + ((long long)(blockIdx.y * gridDim.x + blockIdx.x) * p_max) * kN + tid;
   const c32* __restrict__ Hr = u.Hr + tid;
   float pk_x = 0.f, pk_y = 0.f;
+  c32 nx[16];                                           // the next pair's windows, loaded a pair ahead
+  load_windows(nx, u, k0 - (P - 1), k0 - (P - 1) + kh, k0 - (P - 1) + kh < k1, tid, pk_x);
   for (int i = -(P - 1); i < kh; ++i) {
     const int ka = k0 + i, kb = ka + kh;
     const bool b_valid = kb < k1;
     c32 v[16];
-    load_windows(v, u, ka, kb, b_valid, tid, pk_x);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = nx[r];
+    if (i + 1 < kh) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) nx[r] = c32{v[r + 8].x, kb + 1 < k1 ? v[r + 8].y : 0.f};
+      load_windows<8>(nx, u, ka + 1, kb + 1, kb + 1 < k1, tid, pk_x);
+    }
     fft4096(v, buf, t, tid);
     // Z_i: into the ring (for the pairs to come) and, times H_0, into the sum; then the earlier pairs
     const int slot = (i + 64 * P) % P;
@@ -273,28 +283,46 @@ __global__ __launch_bounds__(256) void reverb_fft_kernel(const ReverbArgs a, con
 // Pairs of utterance b: nblk = k_last - k_first + 1 blocks, Kh = ceil(nblk / 2); pair i = blocks k_first + i and
 // k_first + i + Kh, i in [-(P - 1), Kh): the first P - 1 exist for their spectra only.  Pair i is row q = i + P - 1 of
 // Z (b, pairs_cap, N); the products of pair i >= 0 are row i of Y (b, kh_cap, N), components swapped.
+// (A workgroup takes kPairsPerWg consecutive pairs and loads the next pair's operands before it transforms the
+// current one: a workgroup that lives for one transform waits for its loads with nothing else to do.)
+constexpr int kPairsPerWg = 8;
 __global__ __launch_bounds__(256) void reverb_fwd_kernel(const ReverbArgs a, const float2* __restrict__ tw, int p_max,
                                                          float2* __restrict__ Z, int pairs_cap) {
   __shared__ c32 buf[kBufLen];
-  const int tid = threadIdx.x, b = blockIdx.y, q = blockIdx.x;
+  const int tid = threadIdx.x, b = blockIdx.y, q0 = blockIdx.x * kPairsPerWg;
   const Utt u = utterance(a, b, nullptr, p_max);
   if (u.len == 0) return;
-  if (u.ri < 0) {                                       // copied through, 4096 samples per workgroup
-    for (long long n = (long long)q * kN + tid; n < (long long)(q + 1) * kN && n < u.len; n += 256) u.o[n] = u.x[n];
+  if (u.ri < 0) {                                       // copied through, 4096 samples per pair of the grid
+    const long long lo = (long long)q0 * kN, hi = lo + (long long)kPairsPerWg * kN;
+    for (long long n = lo + tid; n < hi && n < u.len; n += 256) u.o[n] = u.x[n];
     return;
   }
-  const int kh = (u.k_last - u.k_first + 2) / 2, i = q - (u.P - 1);
-  if (i >= kh) return;
-  const int ka = u.k_first + i, kb = ka + kh;
+  const int kh = (u.k_last - u.k_first + 2) / 2;
+  const int q1 = (q0 + kPairsPerWg < kh + u.P - 1) ? q0 + kPairsPerWg : kh + u.P - 1;
+  if (q0 >= q1) return;
   Twiddles t;
   make_twiddles(t, tw, tid);
   float pk_x = 0.f;
-  c32 v[16];
-  load_windows(v, u, ka, kb, kb <= u.k_last, tid, pk_x);
-  fft4096(v, buf, t, tid);
-  c32* __restrict__ z = Z + ((long long)b * pairs_cap + q) * kN + tid;
+  c32 nx[16];
+  {
+    const int ka = u.k_first + q0 - (u.P - 1);
+    load_windows(nx, u, ka, ka + kh, ka + kh <= u.k_last, tid, pk_x);
+  }
+  for (int q = q0; q < q1; ++q) {
+    c32 v[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) z[256 * k] = v[k];
+    for (int r = 0; r < 16; ++r) v[r] = nx[r];
+    if (q + 1 < q1) {
+      const int ka = u.k_first + q + 1 - (u.P - 1);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) nx[r] = c32{v[r + 8].x, ka + kh <= u.k_last ? v[r + 8].y : 0.f};
+      load_windows<8>(nx, u, ka, ka + kh, ka + kh <= u.k_last, tid, pk_x);
+    }
+    fft4096(v, buf, t, tid);
+    c32* __restrict__ z = Z + ((long long)b * pairs_cap + q) * kN + tid;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) z[256 * k] = v[k];
+  }
   put_peaks(a, b, tid, pk_x, 0.f, true, false);
 }
 
@@ -302,7 +330,8 @@ __global__ __launch_bounds__(256) void reverb_fwd_kernel(const ReverbArgs a, con
 // utterance: H_p[n], p < P8, sit in its column of an LDS array, the last P8 + 8 spectra's bin in its column of a ring;
 // eight pairs at a time, their eight operands in registers and shifted by one pair per partition (the sliding
 // window of reverb_window_kernel), so a partition costs two LDS reads for eight complex products.  Columns are
-// private to their thread: no barrier anywhere.
+// private to their thread: no barrier anywhere.  (Tried: H_p read from global memory / L2 instead of LDS, which halves
+// the LDS and doubles the resident workgroups: 48 000 taps 2.29 -> 2.11 ms, 8 000 - 32 000 taps 1 - 3 % slower; not kept.)
 constexpr int kMacThreads = 128, kMacT = 8;
 __global__ __launch_bounds__(kMacThreads) void reverb_mac_kernel(const ReverbArgs a, const float2* __restrict__ H, int p_max,
                                                                  const float2* __restrict__ Z, int pairs_cap,
@@ -363,21 +392,31 @@ __global__ __launch_bounds__(kMacThreads) void reverb_mac_kernel(const ReverbArg
 __global__ __launch_bounds__(256) void reverb_inv_kernel(const ReverbArgs a, const float2* __restrict__ tw, int p_max,
                                                          const float2* __restrict__ Y, int kh_cap) {
   __shared__ c32 buf[kBufLen];
-  const int tid = threadIdx.x, b = blockIdx.y, i = blockIdx.x;
+  const int tid = threadIdx.x, b = blockIdx.y, i0 = blockIdx.x * kPairsPerWg;
   const Utt u = utterance(a, b, nullptr, p_max);
   if (u.len == 0 || u.ri < 0) return;
   const int kh = (u.k_last - u.k_first + 2) / 2;
-  if (i >= kh) return;
-  const int ka = u.k_first + i, kb = ka + kh;
+  const int i1 = i0 + kPairsPerWg < kh ? i0 + kPairsPerWg : kh;
+  if (i0 >= i1) return;
   Twiddles t;
   make_twiddles(t, tw, tid);
-  const c32* __restrict__ y = Y + ((long long)b * kh_cap + i) * kN + tid;
-  c32 v[16];
+  const c32* __restrict__ y = Y + ((long long)b * kh_cap) * kN + tid;
+  c32 nx[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) v[k] = y[256 * k];
-  fft4096(v, buf, t, tid);
+  for (int k = 0; k < 16; ++k) nx[k] = y[(long long)i0 * kN + 256 * k];
   float pk_y = 0.f;
-  store_blocks(v, u, ka, kb, kb <= u.k_last, tid, pk_y);
+  for (int i = i0; i < i1; ++i) {
+    c32 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = nx[k];
+    if (i + 1 < i1) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) nx[k] = y[(long long)(i + 1) * kN + 256 * k];
+    }
+    fft4096(v, buf, t, tid);
+    const int ka = u.k_first + i, kb = ka + kh;
+    store_blocks(v, u, ka, kb, kb <= u.k_last, tid, pk_y);
+  }
   put_peaks(a, b, tid, 0.f, pk_y, false, true);
 }
 
@@ -408,14 +447,15 @@ hipError_t launch_reverb_fft3(const ReverbArgs& a, int batch, const float2* tw, 
     if (e != hipSuccess) return e;
   }
   // copied-through utterances take 4096 samples per workgroup of the first kernel: pairs_cap >= out_stride / 4096
-  hipLaunchKernelGGL(reverb_fwd_kernel, dim3(pairs_cap, batch), dim3(256), 0, stream, a, tw, p_max, Z, pairs_cap);
+  const int per = kPairsPerWg;
+  hipLaunchKernelGGL(reverb_fwd_kernel, dim3((pairs_cap + per - 1) / per, batch), dim3(256), 0, stream, a, tw, p_max, Z, pairs_cap);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(reverb_mac_kernel, dim3(kN / kMacThreads, batch), dim3(kMacThreads), lds, stream, a, H, p_max, Z,
                      pairs_cap, Y, kh_cap, p8);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(reverb_inv_kernel, dim3(kh_cap, batch), dim3(256), 0, stream, a, tw, p_max, Y, kh_cap);
+  hipLaunchKernelGGL(reverb_inv_kernel, dim3((kh_cap + per - 1) / per, batch), dim3(256), 0, stream, a, tw, p_max, Y, kh_cap);
   return hipGetLastError();
 }
 
