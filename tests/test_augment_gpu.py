@@ -610,3 +610,25 @@ def test_reverb_spectra_cache_follows_the_bank():
     short = [_rir(24, 100), _rir(25, 64)]
     check(fe.reverb(x, lens, NoiseBank(short, fe.device), idx, host_lengths=host), short, idx)
     check(fe.reverb(x, lens, nb2, idx, host_lengths=host), one, idx)
+
+
+def test_reverb_fft_batches_beyond_the_workspace_limit_run_in_slices(monkeypatch):
+    """The three-kernel form's workspace (two spectra per block pair) is bounded per launch (4 GB; WFE_RV_WS_MB for
+    this test): a batch that needs more runs in slices of as many utterances as fit -- here 4 of 10 per launch --
+    with the bits of the unsliced call."""
+    from wfe_amd.frontend import HipFrontEnd, NoiseBank
+    monkeypatch.delenv("WFE_TUNE", raising=False)
+    fe_whole = HipFrontEnd(n_mel=80, device=0)
+    monkeypatch.setenv("WFE_RV_WS_MB", "5")            # 70 000 samples, 5 partitions: 40 spectra of 32 KB = 1.25 MB per utterance
+    fe_sliced = HipFrontEnd(n_mel=80, device=0)
+    n = 70000
+    x = 0.1 * torch.randn((10, n), generator=torch.Generator(device="cuda").manual_seed(3), device="cuda")
+    host = [n, n // 3, 5, 2049, 0, 4096, 2048, 1, 69999, 12288]
+    lens = torch.tensor(host, dtype=torch.int32, device="cuda")
+    clips = [_rir(31, 9000), _rir(32, 700)]
+    idx = [0, 1, 0, 1, 0, -1, 0, 0, 1, 0]
+    a = fe_whole.reverb(x, lens, NoiseBank(clips, fe_whole.device), idx, host_lengths=host)
+    b = fe_sliced.reverb(x, lens, NoiseBank(clips, fe_sliced.device), idx, host_lengths=host)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert a[0].abs().max() > 0

@@ -69,6 +69,7 @@ struct wfe_context {
   std::vector<char> ev_cont;                // per event triple: 1 = second half of the same call (not a launch of its own)
   int out_kind = WFE_OUT_F32;               // wfe_set_output_format
   int tune = 0;                             // WFE_TUNE (experiments)
+  size_t rv_ws_limit = (size_t)4 << 30;     // bytes of FFT-reverb workspace per launch (WFE_RV_WS_MB): larger batches run in slices
   std::string err;
 };
 
@@ -164,10 +165,9 @@ void fill_args(wfe_context* h, wfe::FrontArgs& a, const void* wav_or_pcm, int ch
 struct Slice {
   int begin, count;
 };
-std::vector<Slice> slices(int batch) {
+std::vector<Slice> slices(int batch, int limit = kMaxBatchPerLaunch) {
   std::vector<Slice> v;
-  for (int b = 0; b < batch; b += kMaxBatchPerLaunch)
-    v.push_back({b, batch - b < kMaxBatchPerLaunch ? batch - b : kMaxBatchPerLaunch});
+  for (int b = 0; b < batch; b += limit) v.push_back({b, batch - b < limit ? batch - b : limit});
   return v;
 }
 
@@ -365,6 +365,8 @@ int wfe_create(const wfe_config* cfg, wfe_handle* out) {
   if (!h) return fail(nullptr, WFE_ERR_ALLOC, "out of host memory");
   h->cfg = *cfg;
   if (const char* t = std::getenv("WFE_TUNE")) h->tune = std::atoi(t);
+  if (const char* t = std::getenv("WFE_RV_WS_MB"))
+    if (std::atoll(t) > 0) h->rv_ws_limit = (size_t)std::atoll(t) << 20;
   h->mel_filters.resize((size_t)wfe::kNfreq * cfg->n_mel);
   wfe_build_mel_filters(cfg->n_mel, h->mel_filters.data());
   std::vector<float> dft((size_t)wfe::kDftTableFloats), mel((size_t)wfe::kMelTableFloats);
@@ -667,7 +669,16 @@ int wfe_reverb(wfe_handle h, const float* wav, const int64_t* offsets, const int
     }
     use_fft = h->rv_max_taps >= wfe::kRvFftMinTaps;
   }
-  for (const Slice& s : slices(batch)) {
+  // The three-kernel form keeps two spectra per block pair in its workspace (0.26 MB per second of audio): batches
+  // whose workspace would exceed rv_ws_limit (4 GB: 512 utterances of 30 s) run in slices of as many as fit.
+  int limit = kMaxBatchPerLaunch;
+  if (use_fft && h->rv_p_max >= 3) {
+    const long long blocks = (out_stride + wfe::kRvFftN / 2 - 1) / (wfe::kRvFftN / 2) + 1;
+    const size_t per_utt = (size_t)(2 * ((blocks + 1) / 2) + h->rv_p_max - 1) * wfe::kRvFftN * sizeof(float2);
+    const size_t fit = h->rv_ws_limit / per_utt;
+    if (fit < (size_t)limit) limit = fit < 1 ? 1 : (int)fit;
+  }
+  for (const Slice& s : slices(batch, limit)) {
     wfe::ReverbArgs a;
     std::memset(&a, 0, sizeof a);
     a.wav = offsets ? wav : wav + (long long)s.begin * row_stride;
