@@ -630,6 +630,10 @@ int wfe_reverb(wfe_handle h, const float* wav, const int64_t* offsets, const int
   bool use_fft = false;
   if (n_rir > 0 && !(h->tune & 8192)) {
     if (h->rv_rir_seen != rir || h->rv_off_seen != rir_offsets || h->rv_n_seen != n_rir) {
+      h->rv_rir_seen = nullptr;                        // (nothing is cached until all of this has succeeded)
+      h->rv_off_seen = nullptr;
+      h->rv_n_seen = 0;
+      h->rv_max_taps = 0;
       std::vector<int64_t> off((size_t)n_rir + 1);
       HIP_TRY(h, hipMemcpyAsync(off.data(), rir_offsets, off.size() * sizeof(int64_t), hipMemcpyDeviceToHost, stream));
       HIP_TRY(h, hipStreamSynchronize(stream));
@@ -639,10 +643,6 @@ int wfe_reverb(wfe_handle h, const float* wav, const int64_t* offsets, const int
         if (t < 0 || t >= (1LL << 30)) return fail(h, WFE_ERR_ARG, "impulse response %d: bad length", j);
         if (t > max_taps) max_taps = (int)t;
       }
-      h->rv_rir_seen = rir;
-      h->rv_off_seen = rir_offsets;
-      h->rv_n_seen = n_rir;
-      h->rv_max_taps = max_taps;
       h->rv_p_max = (max_taps + wfe::kRvFftN / 2 - 1) / (wfe::kRvFftN / 2);
       if (max_taps >= wfe::kRvFftMinTaps) {
         if (!h->d_rv_tw) {
@@ -666,6 +666,10 @@ int wfe_reverb(wfe_handle h, const float* wav, const int64_t* offsets, const int
         HIP_TRY(h, wfe::launch_reverb_spectra(rir, reinterpret_cast<const long long*>(rir_offsets), n_rir, h->rv_p_max,
                                               h->d_rv_tw, h->d_rv_H, stream));
       }
+      h->rv_rir_seen = rir;
+      h->rv_off_seen = rir_offsets;
+      h->rv_n_seen = n_rir;
+      h->rv_max_taps = max_taps;
     }
     use_fft = h->rv_max_taps >= wfe::kRvFftMinTaps;
   }
