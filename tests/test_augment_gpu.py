@@ -521,14 +521,15 @@ def _reverb_float64(x, h):
 
 
 @pytest.mark.parametrize("taps,tune", [(512, 0), (2048, 0), (2049, 0), (4096, 0), (4097, 0), (6144, 0), (6145, 0), (6145, 16384),
-                                       (16000, 0), (16000, 16384), (16385, 0), (40000, 0)])
+                                       (16000, 0), (16000, 16384), (16385, 0), (40000, 0), (66000, 0)])
 def test_reverb_fft_forms_match_float64_convolution(monkeypatch, taps, tune):
     """Impulse-response banks whose longest response has 512 taps or more take the partitioned overlap-save FFT form
     (wfe_reverb_fft.hip): one kernel up to three partitions of 2048 taps, three kernels beyond (WFE_TUNE & 16384: one
     kernel for every length).  Against add_reverb in float64, with the bound of the direct sum's test
     (3e-6 max|y| sqrt(taps / 64); measured ~1e-7, below the direct sum's own error), on ragged utterances -- empty,
     shorter than a block, shorter than the response, block-aligned -- with responses of different partition counts
-    in one bank, one utterance copied through; rows zero behind their lengths; and close to the direct-sum kernel."""
+    in one bank, one utterance copied through; rows zero behind their lengths; and close to the direct-sum kernel.
+    (66 000 taps = 33 partitions: the products' kernel asks for 88 KB of dynamic LDS, beyond the default 64 KB.)"""
     from wfe_amd.frontend import HipFrontEnd, NoiseBank
     monkeypatch.setenv("WFE_TUNE", str(tune))
     fe_fft = HipFrontEnd(n_mel=80, device=0)
